@@ -1,0 +1,27 @@
+"""pytest config: registers the `gpu` marker and puts the product source root
+(`algonauts-2025_amd/`, which holds the drop-in packages `algonauts2025`,
+`modeling_utils`, `data_utils` and the ctypes binding `tribe_hip`) on sys.path."""
+
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC = ROOT / "algonauts-2025_amd"
+for p in (str(ROOT), str(SRC)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
