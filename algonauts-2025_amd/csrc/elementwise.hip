@@ -1,0 +1,339 @@
+// HBM-bound kernels of the TRIBE encode path: packing / layout changes, ScaleNorm,
+// rotary, softmax, V transpose, adaptive average pool.  All are pure streaming
+// kernels (roofline: HBM bandwidth); loads/stores are 8-16 B per lane where the
+// layout allows.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// f32 [rows, cols] -> bf16 [rows_pad, cols_pad] (zero padded); 8 outputs per thread
+// ---------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld_src,
+                                   unsigned short* __restrict__ dst, int64_t rows_pad, int64_t cols_pad) {
+  const int64_t chunks = cols_pad >> 3;
+  const int64_t total = rows_pad * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / chunks, c = (i - r * chunks) << 3;
+    u16x8_t o;
+    if (r < rows && c + 8 <= cols && (ld_src & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+      const float4 v0 = *(const float4*)(src + r * ld_src + c);
+      const float4 v1 = *(const float4*)(src + r * ld_src + c + 4);
+      o[0] = f32_to_bf16(v0.x); o[1] = f32_to_bf16(v0.y); o[2] = f32_to_bf16(v0.z); o[3] = f32_to_bf16(v0.w);
+      o[4] = f32_to_bf16(v1.x); o[5] = f32_to_bf16(v1.y); o[6] = f32_to_bf16(v1.z); o[7] = f32_to_bf16(v1.w);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (r < rows && c + k < cols) ? f32_to_bf16(src[r * ld_src + c + k]) : 0;
+    }
+    *(u16x8_t*)(dst + r * cols_pad + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// generic tiled transpose+cast:  out[z][j][i] (bf16, ld_out, zero padded to i_pad x j_pad)
+//   = reduce_l in[z][l][i][j]   with in element strides (s_z, s_l, s_i, 1), j contiguous.
+// 64x64 tile through LDS: reads coalesced along j, writes coalesced along i.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float ld_as_f32(const T* p);
+template <>
+__device__ __forceinline__ float ld_as_f32<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld_as_f32<double>(const double* p) { return (float)*p; }
+template <>
+__device__ __forceinline__ float ld_as_f32<unsigned short>(const unsigned short* p) { return bf16_to_f32(*p); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const T* __restrict__ in, int64_t s_z, int64_t s_l, int64_t s_i,
+                                                             int64_t L, float l_scale, int64_t I, int64_t J,
+                                                             unsigned short* __restrict__ out, int64_t so_z, int64_t ld_out,
+                                                             int64_t I_pad, int64_t J_pad) {
+  __shared__ float tile[64][65];
+  const int64_t z = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const T* src = in + z * s_z;
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t i = i0 + r, j = j0 + tx;
+    float v = 0.f;
+    if (i < I && j < J) {
+      const T* p = src + i * s_i + j;
+      for (int64_t l = 0; l < L; ++l) v += ld_as_f32<T>(p + l * s_l);
+      v *= l_scale;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  unsigned short* dst = out + z * so_z;
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t j = j0 + r, i = i0 + tx;
+    if (j < J_pad && i < I_pad) dst[j * ld_out + i] = f32_to_bf16(tile[tx][r]);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// ScaleNorm: one wave per row;  y = x * (gain / max(||x||, eps))
+// ---------------------------------------------------------------------------------
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void scalenorm_kernel(const float* __restrict__ x, int64_t rows, int64_t dim,
+                                                        const float* __restrict__ g, float gain_scale, float eps,
+                                                        void* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = (const float4*)(x + row * dim);
+  const int64_t n4 = dim >> 2;
+  float ss = 0.f;
+  for (int64_t i = lane; i < n4; i += 64) {
+    const float4 v = xr[i];
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float scale = (g[0] * gain_scale) / fmaxf(sqrtf(ss), eps);
+  for (int64_t i = lane; i < n4; i += 64) {
+    const float4 v = xr[i];  // second touch is an L2 hit (12 KiB row)
+    if (OUT_BF16) {
+      u16x4_t o;
+      o[0] = f32_to_bf16(v.x * scale); o[1] = f32_to_bf16(v.y * scale);
+      o[2] = f32_to_bf16(v.z * scale); o[3] = f32_to_bf16(v.w * scale);
+      ((u16x4_t*)((unsigned short*)y + row * dim))[i] = o;
+    } else {
+      ((float4*)((float*)y + row * dim))[i] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// partial rotary embedding, in place on the q and k sections of a fused qkv buffer
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rotary_kernel(unsigned short* __restrict__ qkv, int64_t rows, int64_t T, int heads,
+                                                     int dim_head, int rot_dim, const float* __restrict__ cos_tab,
+                                                     const float* __restrict__ sin_tab, int interleaved) {
+  const int half = rot_dim >> 1;
+  const int items_per_head = half >> 2;  // each item rotates 4 pairs (8 elements)
+  const int64_t inner = (int64_t)heads * dim_head;
+  const int64_t total = rows * 2 * heads * items_per_head;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int it = (int)(t % items_per_head); t /= items_per_head;
+    const int h = (int)(t % heads); t /= heads;
+    const int sec = (int)(t & 1);
+    const int64_t row = t >> 1;
+    const int64_t pos = row % T;
+    unsigned short* base = qkv + row * 3 * inner + sec * inner + (int64_t)h * dim_head;
+    const float4 c = *(const float4*)(cos_tab + pos * half + it * 4);
+    const float4 s = *(const float4*)(sin_tab + pos * half + it * 4);
+    const float cs[4] = {c.x, c.y, c.z, c.w}, sn[4] = {s.x, s.y, s.z, s.w};
+    if (interleaved) {
+      u16x8_t v = *(u16x8_t*)(base + it * 8);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float a = bf16_to_f32(v[2 * p]), b = bf16_to_f32(v[2 * p + 1]);
+        v[2 * p] = f32_to_bf16(a * cs[p] - b * sn[p]);
+        v[2 * p + 1] = f32_to_bf16(b * cs[p] + a * sn[p]);
+      }
+      *(u16x8_t*)(base + it * 8) = v;
+    } else {
+      u16x4_t lo = *(u16x4_t*)(base + it * 4), hi = *(u16x4_t*)(base + half + it * 4);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float a = bf16_to_f32(lo[p]), b = bf16_to_f32(hi[p]);
+        lo[p] = f32_to_bf16(a * cs[p] - b * sn[p]);
+        hi[p] = f32_to_bf16(b * cs[p] + a * sn[p]);
+      }
+      *(u16x4_t*)(base + it * 4) = lo;
+      *(u16x4_t*)(base + half + it * 4) = hi;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// row softmax: S f32 [R, T] (ld_s) -> P bf16 [R, T_pad] (ld_p), zero padded; one wave per row
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ S, int64_t R, int64_t T, int64_t ld_s,
+                                                      unsigned short* __restrict__ P, int64_t T_pad, int64_t ld_p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* s = S + row * ld_s;
+  float m = -INFINITY;
+  for (int64_t i = lane; i < T; i += 64) m = fmaxf(m, s[i]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int64_t i = lane; i < T; i += 64) sum += __expf(s[i] - m);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  unsigned short* p = P + row * ld_p;
+  for (int64_t i = lane; i < T_pad; i += 64) p[i] = (i < T) ? f32_to_bf16(__expf(s[i] - m) * inv) : (unsigned short)0;
+}
+
+// ---------------------------------------------------------------------------------
+// adaptive average pool along the last axis: x f32 [rows, T_in] -> y [rows, T_out]
+// ---------------------------------------------------------------------------------
+__global__ void adaptive_pool_kernel(const float* __restrict__ x, int64_t rows, int64_t T_in, float* __restrict__ y,
+                                     int64_t T_out) {
+  const int64_t total = rows * T_out;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / T_out, i = idx - r * T_out;
+    const int64_t a = (i * T_in) / T_out;
+    const int64_t b = ((i + 1) * T_in + T_out - 1) / T_out;
+    const float* p = x + r * T_in;
+    float acc = 0.f;
+    for (int64_t t = a; t < b; ++t) acc += p[t];
+    y[idx] = acc / (float)(b - a);
+  }
+}
+
+// x[m][col0 + n] (=|+=) rowadd[m % T][col0 + n] + gadd[idx[m / T]][col0 + n]   (zero-projector block)
+__global__ void fill_embed_kernel(float* __restrict__ x, int64_t BT, int64_t T, int64_t N_out, int64_t hidden, int64_t col0,
+                                  const float* __restrict__ pos, const float* __restrict__ subj,
+                                  const int64_t* __restrict__ sid) {
+  const int64_t total = BT * N_out;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / N_out, n = col0 + (idx - m * N_out);
+    float v = 0.f;
+    if (pos) v += pos[(m % T) * hidden + n];
+    if (subj) v += subj[sid[m / T] * hidden + n];
+    x[m * hidden + n] = v;
+  }
+}
+
+inline unsigned grid_for(int64_t total, int block) {
+  int64_t b = (total + block - 1) / block;
+  if (b > 256 * 8) b = 256 * 8;  // cap and grid-stride (guide: memory-bound grid sizing)
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int tribe_pack_weight_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld_src, uint16_t* dst,
+                                      int64_t rows_pad, int64_t cols_pad, void* stream) {
+  TRIBE_REQUIRE(src && dst, "tribe_pack_weight_bf16: null pointer");
+  TRIBE_REQUIRE(rows > 0 && cols > 0 && rows_pad >= rows && cols_pad >= cols && ld_src >= cols,
+                "tribe_pack_weight_bf16: bad shape rows=%lld cols=%lld rows_pad=%lld cols_pad=%lld ld=%lld", (long long)rows,
+                (long long)cols, (long long)rows_pad, (long long)cols_pad, (long long)ld_src);
+  TRIBE_REQUIRE(cols_pad % 8 == 0 && ((uintptr_t)dst % 16) == 0, "tribe_pack_weight_bf16: cols_pad %% 8 and 16-byte dst required");
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(rows_pad * (cols_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     rows, cols, ld_src, dst, rows_pad, cols_pad);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_pack_subject_weights(const float* w, int64_t S, int64_t C, int64_t V, uint16_t* dst, int64_t V_pad,
+                                          int64_t C_pad, void* stream) {
+  TRIBE_REQUIRE(w && dst, "tribe_pack_subject_weights: null pointer");
+  TRIBE_REQUIRE(S > 0 && C > 0 && V > 0 && V_pad >= V && C_pad >= C && C_pad % 8 == 0,
+                "tribe_pack_subject_weights: bad shape S=%lld C=%lld V=%lld V_pad=%lld C_pad=%lld", (long long)S, (long long)C,
+                (long long)V, (long long)V_pad, (long long)C_pad);
+  // in[s][c][v] -> out[s][v][c]:  I = C (i index), J = V (contiguous in the source)
+  dim3 grid((unsigned)((C_pad + 63) / 64), (unsigned)((V_pad + 63) / 64), (unsigned)S);
+  hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, C * V, (int64_t)0, V, (int64_t)1,
+                     1.0f, C, V, dst, V_pad * C_pad, C_pad, C_pad, V_pad);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_pack_features(const void* feat, int32_t dtype, int64_t B, int64_t L, int64_t D, int64_t T,
+                                   int32_t layer_mean, uint16_t* dst, int64_t K_pad, void* stream) {
+  TRIBE_REQUIRE(feat && dst, "tribe_pack_features: null pointer");
+  TRIBE_REQUIRE(B > 0 && L > 0 && D > 0 && T > 0, "tribe_pack_features: bad shape B=%lld L=%lld D=%lld T=%lld", (long long)B,
+                (long long)L, (long long)D, (long long)T);
+  const int64_t K = layer_mean ? D : L * D;
+  TRIBE_REQUIRE(K_pad >= K && K_pad % 8 == 0, "tribe_pack_features: K_pad=%lld must be >= %lld and a multiple of 8",
+                (long long)K_pad, (long long)K);
+  TRIBE_REQUIRE(B < 65536, "tribe_pack_features: batch too large for one launch");
+  // in[b][k][t] (k = l*D + d for "cat"; reduce over l for "mean") -> out[b][t][k]
+  const int64_t s_z = L * D * T, s_i = T;
+  const int64_t Lr = layer_mean ? L : 1, s_l = layer_mean ? D * T : 0;
+  const float l_scale = layer_mean ? 1.0f / (float)L : 1.0f;
+  dim3 grid((unsigned)((K_pad + 63) / 64), (unsigned)((T + 63) / 64), (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+#define TRIBE_PF(TYPE)                                                                                                   \
+  hipLaunchKernelGGL(transpose_cast_kernel<TYPE>, grid, dim3(256), 0, s, (const TYPE*)feat, s_z, s_l, s_i, Lr, l_scale, K, T, \
+                     dst, T * K_pad, K_pad, K_pad, T)
+  if (dtype == TRIBE_F32) TRIBE_PF(float);
+  else if (dtype == TRIBE_F64) TRIBE_PF(double);
+  else if (dtype == TRIBE_BF16) TRIBE_PF(unsigned short);
+  else TRIBE_REQUIRE(false, "tribe_pack_features: unsupported dtype %d", dtype);
+#undef TRIBE_PF
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_scalenorm_fwd(const float* x, int64_t rows, int64_t dim, const float* g, float gain_scale, float eps,
+                                   void* y, int32_t y_dtype, void* stream) {
+  TRIBE_REQUIRE(x && g && y, "tribe_scalenorm_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0, "tribe_scalenorm_fwd: rows=%lld dim=%lld (dim %% 4 required)",
+                (long long)rows, (long long)dim);
+  TRIBE_REQUIRE(y_dtype == TRIBE_F32 || y_dtype == TRIBE_BF16, "tribe_scalenorm_fwd: y_dtype must be f32 or bf16");
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (y_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL(scalenorm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, g, gain_scale, eps, y);
+  else
+    hipLaunchKernelGGL(scalenorm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, g, gain_scale, eps, y);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_rotary_fwd(uint16_t* qkv, int64_t rows, int64_t T, int32_t heads, int32_t dim_head, int32_t rot_dim,
+                                const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream) {
+  if (rot_dim == 0) return 0;
+  TRIBE_REQUIRE(qkv && cos_tab && sin_tab, "tribe_rotary_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && T > 0 && heads > 0 && dim_head > 0, "tribe_rotary_fwd: bad shape");
+  TRIBE_REQUIRE(rot_dim > 0 && rot_dim <= dim_head && rot_dim % 8 == 0 && dim_head % 8 == 0,
+                "tribe_rotary_fwd: rot_dim=%d must be a multiple of 8 and <= dim_head=%d (dim_head %% 8 == 0)", rot_dim, dim_head);
+  const int64_t total = rows * 2 * heads * (rot_dim / 8);
+  hipLaunchKernelGGL(rotary_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, rows, T, heads,
+                     dim_head, rot_dim, cos_tab, sin_tab, interleaved);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_adaptive_avg_pool_fwd(const float* x, int64_t rows, int64_t T_in, float* y, int64_t T_out, void* stream) {
+  TRIBE_REQUIRE(x && y, "tribe_adaptive_avg_pool_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && T_in > 0 && T_out > 0, "tribe_adaptive_avg_pool_fwd: bad shape rows=%lld T_in=%lld T_out=%lld",
+                (long long)rows, (long long)T_in, (long long)T_out);
+  hipLaunchKernelGGL(adaptive_pool_kernel, dim3(grid_for(rows * T_out, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, T_in,
+                     y, T_out);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_projector_zero_fwd(int64_t BT, int64_t T, int64_t N_out, float* x, int64_t hidden, int64_t col0,
+                                        const float* pos_embed, const float* subj_embed, const int64_t* subject_id,
+                                        void* stream) {
+  TRIBE_REQUIRE(x, "tribe_projector_zero_fwd: null pointer");
+  TRIBE_REQUIRE(BT > 0 && T > 0 && BT % T == 0 && N_out > 0 && col0 >= 0 && col0 + N_out <= hidden,
+                "tribe_projector_zero_fwd: bad shape");
+  TRIBE_REQUIRE(!subj_embed || subject_id, "tribe_projector_zero_fwd: subject_embed without subject_id");
+  hipLaunchKernelGGL(fill_embed_kernel, dim3(grid_for(BT * N_out, 256)), dim3(256), 0, (hipStream_t)stream, x, BT, T, N_out,
+                     hidden, col0, pos_embed, subj_embed, subject_id);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- internal helpers used by encoder.hip (same shared object, not part of the public ABI) ----
+int tribe_internal_softmax(const float* S, int64_t R, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, S, R, T, ld_s, P, T_pad, ld_p);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+// V section of qkv [B, T, 3*inner] -> Vt [B*heads, dim_head, T_pad]
+int tribe_internal_transpose_v(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, uint16_t* vt, int64_t T_pad,
+                               hipStream_t stream) {
+  const int64_t inner = (int64_t)heads * dim_head;
+  // per z = (b, h): in[t][d] with row stride 3*inner -> out[d][t];   I = T (i index), J = dim_head (contiguous)
+  for (int64_t b = 0; b < B; ++b) {
+    dim3 grid((unsigned)((T_pad + 63) / 64), (unsigned)((dim_head + 63) / 64), (unsigned)heads);
+    hipLaunchKernelGGL(transpose_cast_kernel<unsigned short>, grid, dim3(256), 0, stream, qkv + b * T * 3 * inner + 2 * inner,
+                       (int64_t)dim_head, (int64_t)0, 3 * inner, (int64_t)1, 1.0f, T, (int64_t)dim_head,
+                       vt + b * heads * dim_head * T_pad, dim_head * T_pad, T_pad, T_pad, (int64_t)dim_head);
+  }
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}

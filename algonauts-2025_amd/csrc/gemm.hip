@@ -1,0 +1,187 @@
+// bf16 MFMA GEMM for gfx950:  C = epi(alpha * A . B^T),  A [M,K], B [N,K], K contiguous.
+//
+// Tile 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 4x4
+// v_mfma_f32_16x16x32_bf16 accumulators).  Operands are staged HBM -> LDS with
+// global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into two LDS
+// buffers; the LDS image is lane-linear (a glds requirement), so the bank-conflict
+// swizzle chunk ^= (row & 7) is applied to the per-lane SOURCE address and undone
+// on the ds_read_b128 fragment read (cdna_hip_programming.md rule 21 / T2).
+// Roofline: MFMA (dense bf16) -- see DESIGN.md "Kernels".
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;     // A + B
+constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // double buffered: 64 KiB
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective "each XCD gets a contiguous chunk of tiles" remap (T1); speed only
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int OUT_BF16>
+__global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int64_t z = blockIdx.y;
+  const int64_t b1 = z / g.batch0, b0 = z - b1 * g.batch0;
+  const int64_t b1g = g.gather1 ? g.gather1[b1] : b1;
+  const unsigned short* A = (const unsigned short*)g.A + (g.gather_a ? b1g : b1) * g.sA1 + b0 * g.sA0;
+  const unsigned short* B = (const unsigned short*)g.B + b1 * g.sB1 + b0 * g.sB0;
+
+  // ---- staging addresses: pass p covers tile rows [32p, 32p+32), wave w rows 8w.. of those ----
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ srow;  // swizzle on the source chunk
+  const unsigned short* a_src[4];
+  const unsigned short* b_src[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 32 + wave * 8 + srow;
+    int64_t gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;   // clamp: edge rows re-read a valid row, stores are masked
+    int64_t gc = n0 + r; gc = gc < g.N ? gc : g.N - 1;
+    a_src[p] = A + gr * g.lda + schunk * 8;
+    b_src[p] = B + gc * g.ldb + schunk * 8;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * BUF_BYTES + wave * 1024;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[p] + koff), (lptr_t)(base + p * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[p] + koff), (lptr_t)(base + TILE_BYTES + p * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int a_base = (wr * 64 + frow) * 128;
+  const int b_base = TILE_BYTES + (wc * 64 + frow) * 128;
+
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = (((ks * 4 + fq) ^ (frow & 7)) << 4);
+      bf16x8_t a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8_t*)(base + a_base + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8_t*)(base + b_base + j * 2048 + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (int)(g.K / BK);
+  stage(0, 0);
+  __syncthreads();  // hipcc emits vmcnt(0) before the barrier while a glds is in flight
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    compute(cur);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = 4*fq + reg][col = frow] per 16x16 tile ----
+  const int64_t bb = g.gather_bias ? b1g : b1;
+  const float* bias = g.bias ? g.bias + bb * g.sBias1 : nullptr;
+  const float* res = g.res ? g.res + b1 * g.sRes1 + b0 * g.sRes0 : nullptr;
+  char* Cb = (char*)g.C;
+  const int64_t c_off = b1 * g.sC1 + b0 * g.sC0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t m = m0 + wr * 64 + i * 16 + fq * 4 + reg;
+      if (m >= g.M) continue;
+      const float* rowadd = g.rowadd ? g.rowadd + (m % g.rowadd_period) * g.ld_rowadd : nullptr;
+      const float* gadd = g.gadd ? g.gadd + g.gadd_index[m / g.gadd_div] * g.ld_gadd : nullptr;
+      const float brow = (g.bias_mode == TRIBE_BIAS_ROW) ? bias[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n = n0 + wc * 64 + j * 16 + frow;
+        if (n >= g.N) continue;
+        float v = acc[i][j][reg] * g.alpha;
+        if (g.bias_mode == TRIBE_BIAS_COL) v += bias[n];
+        else if (g.bias_mode == TRIBE_BIAS_ROW) v += brow;
+        if (g.act == TRIBE_ACT_GELU) v = gelu_erf(v);
+        if (res) {
+          const float r = res[m * g.ldres + n];
+          v += g.res_scale ? r * g.res_scale[n] : r;
+        }
+        if (rowadd) v += rowadd[n];
+        if (gadd) v += gadd[n];
+        const int64_t idx = c_off + m * g.ldc + n;
+        if (OUT_BF16) ((unsigned short*)Cb)[idx] = f32_to_bf16(v);
+        else ((float*)Cb)[idx] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
+  TRIBE_REQUIRE(d != nullptr, "tribe_gemm_bf16: null descriptor");
+  TRIBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "tribe_gemm_bf16: M, N, K must be positive (got %lld %lld %lld)",
+                (long long)d->M, (long long)d->N, (long long)d->K);
+  TRIBE_REQUIRE(d->K % BK == 0, "tribe_gemm_bf16: K=%lld must be a multiple of %d (zero-pad K)", (long long)d->K, BK);
+  TRIBE_REQUIRE(d->batch1 > 0 && d->batch0 > 0, "tribe_gemm_bf16: batch counts must be positive");
+  TRIBE_REQUIRE(d->A && d->B && d->C, "tribe_gemm_bf16: null operand");
+  TRIBE_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->sA1 % 8 == 0 && d->sA0 % 8 == 0 && d->sB1 % 8 == 0 &&
+                    d->sB0 % 8 == 0,
+                "tribe_gemm_bf16: lda/ldb/batch strides must be multiples of 8 elements (16-byte rows)");
+  TRIBE_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "tribe_gemm_bf16: A/B must be 16-byte aligned");
+  TRIBE_REQUIRE(d->lda >= d->K && d->ldb >= d->K && d->ldc >= d->N, "tribe_gemm_bf16: leading dimension too small");
+  TRIBE_REQUIRE(d->c_dtype == TRIBE_F32 || d->c_dtype == TRIBE_BF16, "tribe_gemm_bf16: c_dtype must be f32 or bf16");
+  TRIBE_REQUIRE(d->bias_mode == TRIBE_BIAS_NONE || d->bias != nullptr, "tribe_gemm_bf16: bias_mode set without bias");
+  TRIBE_REQUIRE(!d->rowadd || d->rowadd_period > 0, "tribe_gemm_bf16: rowadd needs a positive period");
+  TRIBE_REQUIRE(!d->gadd || (d->gadd_index && d->gadd_div > 0), "tribe_gemm_bf16: gadd needs index and divisor");
+  TRIBE_REQUIRE(!(d->gather_a || d->gather_bias) || d->gather1, "tribe_gemm_bf16: gather flags set without gather1");
+  const int64_t tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN;
+  const int64_t nz = d->batch1 * d->batch0;
+  TRIBE_REQUIRE(tiles_m * tiles_n < (1ll << 31) && nz < 65536, "tribe_gemm_bf16: grid too large");
+
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_128x128x64<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_128x128x64<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nz, 1), block(256, 1, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->c_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL(gemm_nt_128x128x64<1>, grid, block, SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
+  else
+    hipLaunchKernelGGL(gemm_nt_128x128x64<0>, grid, block, SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,111 @@
+"""Per-subject voxel head and the projector builder, HIP-backed.
+
+API mirror of /root/reference/modeling_utils/modeling_utils/models/common.py:
+  * `SubjectLayers(in_channels, out_channels, n_subjects, bias, init_id, average_subjects)`
+    with parameters `weights [S, C, D]`, `bias [S, D]` and `forward(x[B, C, T], subjects) -> [B, D, T]`
+    (common.py:14-71);
+  * `MlpConfig(...).build(input_size, output_size)` (common.py:86-141) -- on the hot path
+    `hidden_sizes` is None and it returns a bare `nn.Linear` (common.py:124-128).
+
+Differences that do not change results: the reference gathers one [C, D] weight copy per
+sample (`index_select`, common.py:61) and runs a batched einsum; here one grouped MFMA GEMM
+reads each subject's packed bf16 weights in place (tribe_voxel_head_fwd).
+"""
+
+from __future__ import annotations
+
+import typing as tp
+
+import pydantic
+import torch
+from torch import nn
+
+from tribe_hip import ops
+
+from .._pack import PackCache, f32c
+
+
+class SubjectLayers(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, n_subjects: int, bias: bool = False, init_id: bool = False,
+                 average_subjects: bool = False):
+        super().__init__()
+        self.weights = nn.Parameter(torch.empty(n_subjects, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(n_subjects, out_channels)) if bias else None
+        with torch.no_grad():
+            if init_id:
+                if in_channels != out_channels:
+                    raise ValueError("in_channels and out_channels must be the same for identity initialization.")
+                self.weights[:] = torch.eye(in_channels)[None]
+                if self.bias is not None:
+                    self.bias.zero_()
+            else:
+                self.weights.normal_()
+                if self.bias is not None:
+                    self.bias.normal_()
+            self.weights *= 1 / in_channels**0.5
+            if self.bias is not None:
+                self.bias *= 1 / in_channels**0.5
+        self.average_subjects = average_subjects
+        self._packs = PackCache()
+
+    # -- packed parameter views -------------------------------------------------------
+    def packed(self) -> tuple[torch.Tensor, torch.Tensor | None]:
+        def build():
+            w = f32c(self.weights)
+            b = None if self.bias is None else f32c(self.bias)
+            if self.average_subjects:  # common.py:56-59: one shared head = mean over subjects
+                w = w.mean(dim=0, keepdim=True)
+                b = None if b is None else b.mean(dim=0, keepdim=True)
+            return ops.pack_subject_weights(w), b
+
+        return self._packs.get("w", [self.weights, self.bias], build)
+
+    def check_subjects(self, subjects: torch.Tensor) -> torch.Tensor:
+        subjects = subjects.flatten().to(torch.int64)
+        n = self.weights.shape[0]
+        # common.py:53-55 (one host sync, as in the reference's assert)
+        assert subjects.max() < n, "Subject index higher than number of subjects used to initialize the weights."
+        if self.average_subjects:
+            subjects = torch.zeros_like(subjects)
+        return subjects.contiguous()
+
+    def forward_tokens(self, x_btc: torch.Tensor, subjects: torch.Tensor) -> torch.Tensor:
+        """x bf16 [B, T, C_pad] (token-major, as the encoder leaves it) -> f32 [B, D, T]."""
+        w_packed, bias = self.packed()
+        return ops.voxel_head(x_btc, w_packed, bias, self.check_subjects(subjects), self.weights.shape[2])
+
+    def forward(self, x: torch.Tensor, subjects: torch.Tensor) -> torch.Tensor:
+        """Reference signature: x [B, C, T] (a transposed view of [B, T, C] at model.py:117)."""
+        B, C, T = x.shape
+        if C != self.weights.shape[1]:
+            raise ValueError(f"SubjectLayers: expected {self.weights.shape[1]} channels, got {C}")
+        # pack_features is exactly the cast + "b c t -> b t c" relayout needed here (L = 1)
+        xt = ops.pack_features(x.contiguous(), layer_mean=False).view(B, T, -1)
+        return self.forward_tokens(xt, subjects)
+
+    def __repr__(self) -> str:
+        S, C, D = self.weights.shape
+        return f"SubjectLayers({C}, {D}, {S})"
+
+
+class MlpConfig(pydantic.BaseModel):
+    model_config = pydantic.ConfigDict(extra="forbid")
+    name: tp.Literal["Mlp"] = "Mlp"
+    input_size: int | None = None
+    hidden_sizes: list[int] | None = None
+    norm_layer: tp.Literal["layer", "batch", "instance", "unit", None] = None
+    activation_layer: tp.Literal["relu", "gelu", "elu", "prelu", None] = "relu"
+    bias: bool = True
+    dropout: float = 0.0
+
+    def build(self, input_size: int | None = None, output_size: int | None = None) -> nn.Module:
+        input_size = self.input_size if input_size is None else input_size
+        assert input_size is not None, "input_size cannot be None."
+        if not self.hidden_sizes:
+            assert output_size is not None, "output_size cannot be None if hidden_sizes is empty."
+            # parameter holder; FmriEncoder runs it through tribe_projector_fwd
+            return nn.Linear(input_size, output_size)
+        raise NotImplementedError(
+            "MlpConfig with hidden_sizes builds torchvision.ops.MLP in the reference (common.py:130-141); "
+            "that branch is never reached from algonauts2025/model.py and is outside the HIP hot path."
+        )

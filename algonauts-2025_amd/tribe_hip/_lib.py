@@ -1,0 +1,128 @@
+"""ctypes binding of libtribe_hip.so (C ABI declared in include/tribe_hip.h).
+
+The shared object is built in-tree by `__graft_entry__.build()` / `make -C csrc`.
+There is NO fallback: if the library is missing or a call fails, this module
+raises -- the product path never silently drops to PyTorch or to the oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libtribe_hip.so"
+
+F32, BF16, F64 = 0, 1, 2
+ACT_NONE, ACT_GELU = 0, 1
+BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+
+i64, i32, f32, vp, sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    """struct tribe_gemm_desc"""
+
+    _fields_ = [
+        ("M", i64), ("N", i64), ("K", i64),
+        ("batch1", i64), ("batch0", i64),
+        ("A", vp), ("lda", i64), ("sA1", i64), ("sA0", i64),
+        ("B", vp), ("ldb", i64), ("sB1", i64), ("sB0", i64),
+        ("C", vp), ("ldc", i64), ("sC1", i64), ("sC0", i64),
+        ("c_dtype", i32), ("alpha", f32),
+        ("gather1", vp), ("gather_a", i32), ("gather_bias", i32),
+        ("bias", vp), ("bias_mode", i32), ("sBias1", i64),
+        ("act", i32),
+        ("res", vp), ("ldres", i64), ("sRes1", i64), ("sRes0", i64),
+        ("res_scale", vp),
+        ("rowadd", vp), ("ld_rowadd", i64), ("rowadd_period", i64),
+        ("gadd", vp), ("gadd_index", vp), ("gadd_div", i64), ("ld_gadd", i64),
+    ]
+
+
+class EncoderLayer(C.Structure):
+    """struct tribe_encoder_layer"""
+
+    _fields_ = [
+        ("attn_norm_g", vp), ("w_qkv", vp), ("w_out", vp), ("attn_res_scale", vp),
+        ("ff_norm_g", vp), ("w_ff1", vp), ("b_ff1", vp), ("w_ff2", vp), ("b_ff2", vp), ("ff_res_scale", vp),
+    ]
+
+
+class EncoderDesc(C.Structure):
+    """struct tribe_encoder_desc"""
+
+    _fields_ = [
+        ("B", i64), ("T", i64),
+        ("dim", i32), ("depth", i32), ("heads", i32), ("dim_head", i32), ("ff_inner", i32), ("rot_dim", i32),
+        ("rotary_interleaved", i32),
+        ("norm_gain_scale", f32), ("norm_eps", f32),
+        ("layers_host", C.POINTER(EncoderLayer)),
+        ("final_norm_g", vp),
+        ("cos_tab", vp), ("sin_tab", vp),
+    ]
+
+
+# name -> (restype, argtypes); must cover every symbol include/tribe_hip.h declares
+SIGNATURES = {
+    "tribe_version": (C.c_int, []),
+    "tribe_last_error": (C.c_char_p, []),
+    "tribe_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tribe_pack_weight_bf16": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),
+    "tribe_pack_subject_weights": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),
+    "tribe_pack_features": (C.c_int, [vp, i32, i64, i64, i64, i64, i32, vp, i64, vp]),
+    "tribe_projector_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, i64, vp, i64, i64, i32, vp, vp, vp, vp]),
+    "tribe_projector_zero_fwd": (C.c_int, [i64, i64, i64, vp, i64, i64, vp, vp, vp, vp]),
+    "tribe_scalenorm_fwd": (C.c_int, [vp, i64, i64, vp, f32, f32, vp, i32, vp]),
+    "tribe_rotary_fwd": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, vp, i32, vp]),
+    "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),
+    "tribe_attention_fwd": (C.c_int, [vp, i64, i64, i32, i32, f32, vp, vp, sz, vp]),
+    "tribe_encoder_workspace_bytes": (sz, [C.POINTER(EncoderDesc)]),
+    "tribe_encoder_fwd": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, i32, vp, sz, vp]),
+    "tribe_voxel_head_fwd": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, i64, vp, vp, vp, vp]),
+    "tribe_adaptive_avg_pool_fwd": (C.c_int, [vp, i64, i64, vp, i64, vp]),
+    "tribe_mse_fwd": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),
+    "tribe_mse_workspace_bytes": (sz, [i64]),
+    "tribe_pearson_stats_update": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, vp, i64, vp, vp]),
+    "tribe_pearson_from_stats": (C.c_int, [vp, i64, i64, vp, vp]),
+    "tribe_pearson_loss_fwd": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, i32, vp, vp, sz, vp]),
+    "tribe_pearson_loss_workspace_bytes": (sz, [i64]),
+}
+
+_lib = None
+
+
+class TribeHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the shared object once; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        path = Path(os.environ.get("TRIBE_HIP_LIB", LIB_PATH))
+        if not path.exists():
+            raise TribeHipError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C algonauts-2025_amd/csrc`). There is no CPU / PyTorch fallback for the hot path."
+            )
+        handle = C.CDLL(str(path))
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the export is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.tribe_version() != 1:
+            raise TribeHipError(f"ABI version mismatch: library reports {handle.tribe_version()}, binding expects 1")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    """0 = OK; <0 argument error -> ValueError; >0 hipError_t -> TribeHipError."""
+    if rc == 0:
+        return
+    msg = lib().tribe_last_error().decode(errors="replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg}")
+    raise TribeHipError(f"{what}: HIP error {rc}: {msg}")

@@ -1,0 +1,350 @@
+"""torch-tensor front end of the C ABI: validates shapes / devices on the host (mirroring
+the reference's assert-style checks), hands raw device pointers + the current HIP
+stream to libtribe_hip.so.  torch is used for memory, streams and nothing else."""
+
+from __future__ import annotations
+
+import ctypes as C
+import typing as tp
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, F64, EncoderDesc, EncoderLayer, GemmDesc, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float64: F64}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _cuda(t: torch.Tensor, dtype: torch.dtype | tuple[torch.dtype, ...] | None, name: str, contiguous: bool = True) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.TribeHipError(f"{name}: tensor is on {t.device}; the TRIBE hot path runs on the GPU only (no CPU fallback)")
+    if dtype is not None:
+        ok = t.dtype in dtype if isinstance(dtype, tuple) else t.dtype == dtype
+        if not ok:
+            raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+# --------------------------------------------------------------------------------------
+# workspace: one grow-only byte buffer per device, owned by the torch caching allocator
+# --------------------------------------------------------------------------------------
+_WS: dict[tuple[int, str], torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device: torch.device, tag: str = "main") -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------
+# generic MFMA GEMM
+# --------------------------------------------------------------------------------------
+def gemm_nt(
+    a: torch.Tensor, b: torch.Tensor, *, bias: torch.Tensor | None = None, bias_row: bool = False, act: str | None = None,
+    res: torch.Tensor | None = None, res_scale: torch.Tensor | None = None, alpha: float = 1.0,
+    out_dtype: torch.dtype = torch.float32, out: torch.Tensor | None = None,
+    rowadd: torch.Tensor | None = None, rowadd_period: int = 0,
+    gadd: torch.Tensor | None = None, gadd_index: torch.Tensor | None = None, gadd_div: int = 0,
+) -> torch.Tensor:
+    """out[..., m, n] = epi(alpha * sum_k a[..., m, k] * b[..., n, k]); a, b bf16 with equal leading batch dim (or 2-D)."""
+    _cuda(a, torch.bfloat16, "a")
+    _cuda(b, torch.bfloat16, "b")
+    if a.ndim == 2:
+        a3, b3 = a[None], b[None]
+    else:
+        a3, b3 = a, b
+    if a3.ndim != 3 or b3.ndim != 3 or a3.shape[0] != b3.shape[0] or a3.shape[2] != b3.shape[2]:
+        raise ValueError(f"gemm_nt: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
+    Z, M, K = a3.shape
+    N = b3.shape[1]
+    if out is None:
+        out = torch.empty((Z, M, N) if a.ndim == 3 else (M, N), dtype=out_dtype, device=a.device)
+    _cuda(out, (torch.float32, torch.bfloat16), "out")
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, Z, 1
+    d.A, d.lda, d.sA1 = a3.data_ptr(), K, M * K
+    d.B, d.ldb, d.sB1 = b3.data_ptr(), K, N * K
+    d.C, d.ldc, d.sC1 = out.data_ptr(), N, M * N
+    d.c_dtype = _DT[out.dtype]
+    d.alpha = alpha
+    if bias is not None:
+        _cuda(bias, torch.float32, "bias")
+        d.bias, d.bias_mode = bias.data_ptr(), (_lib.BIAS_ROW if bias_row else _lib.BIAS_COL)
+    d.act = _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE
+    if res is not None:
+        _cuda(res, torch.float32, "res")
+        d.res, d.ldres, d.sRes1 = res.data_ptr(), N, M * N
+    if res_scale is not None:
+        d.res_scale = _cuda(res_scale, torch.float32, "res_scale").data_ptr()
+    if rowadd is not None:
+        _cuda(rowadd, torch.float32, "rowadd")
+        d.rowadd, d.ld_rowadd, d.rowadd_period = rowadd.data_ptr(), rowadd.shape[-1], rowadd_period
+    if gadd is not None:
+        _cuda(gadd, torch.float32, "gadd")
+        _cuda(gadd_index, torch.int64, "gadd_index")
+        d.gadd, d.gadd_index, d.gadd_div, d.ld_gadd = gadd.data_ptr(), gadd_index.data_ptr(), gadd_div, gadd.shape[-1]
+    check(lib().tribe_gemm_bf16(C.byref(d), _stream()), "tribe_gemm_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# packing
+# --------------------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor, rows_pad: int | None = None, cols_pad: int | None = None) -> torch.Tensor:
+    """f32 [rows, cols] -> bf16 [rows_pad, cols_pad] zero padded (cols padded to 64 by default: the GEMM's K step)."""
+    _cuda(w, torch.float32, "w")
+    rows, cols = w.shape
+    rows_pad = rows if rows_pad is None else rows_pad
+    cols_pad = round_up(cols, 64) if cols_pad is None else cols_pad
+    out = torch.empty(rows_pad, cols_pad, dtype=torch.bfloat16, device=w.device)
+    check(lib().tribe_pack_weight_bf16(w.data_ptr(), rows, cols, cols, out.data_ptr(), rows_pad, cols_pad, _stream()),
+          "tribe_pack_weight_bf16")
+    return out
+
+
+def pack_subject_weights(w: torch.Tensor) -> torch.Tensor:
+    """SubjectLayers.weights f32 [S, C, V] -> bf16 [S, V_pad, C_pad] (V_pad % 128 == 0, C_pad % 64 == 0)."""
+    _cuda(w, torch.float32, "weights")
+    S, Cc, V = w.shape
+    V_pad, C_pad = round_up(V, 128), round_up(Cc, 64)
+    out = torch.empty(S, V_pad, C_pad, dtype=torch.bfloat16, device=w.device)
+    check(lib().tribe_pack_subject_weights(w.data_ptr(), S, Cc, V, out.data_ptr(), V_pad, C_pad, _stream()),
+          "tribe_pack_subject_weights")
+    return out
+
+
+def pack_features(feat: torch.Tensor, layer_mean: bool, K_pad: int | None = None) -> torch.Tensor:
+    """[B, L, D, T] or [B, D, T] (f32 / bf16 / f64) -> bf16 [B*T, K_pad] (model.py:146-155)."""
+    _cuda(feat, (torch.float32, torch.bfloat16, torch.float64), "feat")
+    if feat.ndim == 3:
+        feat = feat[:, None]
+    if feat.ndim != 4:
+        raise ValueError(f"pack_features: expected [B, L, D, T] or [B, D, T], got {tuple(feat.shape)}")
+    B, L, D, T = feat.shape
+    K = D if layer_mean else L * D
+    K_pad = round_up(K, 64) if K_pad is None else K_pad
+    out = torch.empty(B * T, K_pad, dtype=torch.bfloat16, device=feat.device)
+    check(lib().tribe_pack_features(feat.data_ptr(), _DT[feat.dtype], B, L, D, T, int(layer_mean), out.data_ptr(), K_pad, _stream()),
+          "tribe_pack_features")
+    return out
+
+
+def projector_fwd(feat_packed: torch.Tensor, T: int, w_packed: torch.Tensor, bias: torch.Tensor | None, n_out: int,
+                  x: torch.Tensor, col0: int, accumulate: bool, pos_embed: torch.Tensor | None,
+                  subj_embed: torch.Tensor | None, subject_id: torch.Tensor | None) -> None:
+    _cuda(feat_packed, torch.bfloat16, "feat_packed")
+    _cuda(w_packed, torch.bfloat16, "w_packed")
+    _cuda(x, torch.float32, "x")
+    BT, K_pad = feat_packed.shape
+    if w_packed.shape[1] != K_pad or w_packed.shape[0] < n_out:
+        raise ValueError(f"projector_fwd: packed weight {tuple(w_packed.shape)} does not match K_pad={K_pad}, n_out={n_out}")
+    if pos_embed is not None and (pos_embed.shape[-1] != x.shape[-1] or pos_embed.shape[-2] < T):
+        raise ValueError(f"projector_fwd: time_pos_embed {tuple(pos_embed.shape)} shorter than T={T}")
+    check(lib().tribe_projector_fwd(feat_packed.data_ptr(), BT, T, K_pad, w_packed.data_ptr(), _p(bias), n_out, x.data_ptr(),
+                                    x.shape[-1], col0, int(accumulate), _p(pos_embed), _p(subj_embed), _p(subject_id), _stream()),
+          "tribe_projector_fwd")
+
+
+def projector_zero_fwd(BT: int, T: int, n_out: int, x: torch.Tensor, col0: int, pos_embed: torch.Tensor | None,
+                       subj_embed: torch.Tensor | None, subject_id: torch.Tensor | None) -> None:
+    _cuda(x, torch.float32, "x")
+    check(lib().tribe_projector_zero_fwd(BT, T, n_out, x.data_ptr(), x.shape[-1], col0, _p(pos_embed), _p(subj_embed),
+                                         _p(subject_id), _stream()), "tribe_projector_zero_fwd")
+
+
+# --------------------------------------------------------------------------------------
+# encoder pieces
+# --------------------------------------------------------------------------------------
+def scalenorm(x: torch.Tensor, g: torch.Tensor, gain_scale: float, eps: float, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    _cuda(x, torch.float32, "x")
+    _cuda(g, torch.float32, "g")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib().tribe_scalenorm_fwd(x.data_ptr(), rows, dim, g.data_ptr(), gain_scale, eps, y.data_ptr(), _DT[out_dtype], _stream()),
+          "tribe_scalenorm_fwd")
+    return y
+
+
+def rotary_(qkv: torch.Tensor, T: int, heads: int, dim_head: int, rot_dim: int, cos: torch.Tensor, sin: torch.Tensor,
+            interleaved: bool) -> torch.Tensor:
+    _cuda(qkv, torch.bfloat16, "qkv")
+    rows = qkv.numel() // (3 * heads * dim_head)
+    if cos.shape != (T, rot_dim // 2) or sin.shape != cos.shape:
+        raise ValueError(f"rotary_: tables must be [T, rot_dim/2] = {(T, rot_dim // 2)}, got {tuple(cos.shape)}")
+    check(lib().tribe_rotary_fwd(qkv.data_ptr(), rows, T, heads, dim_head, rot_dim, _cuda(cos, torch.float32, "cos").data_ptr(),
+                                 _cuda(sin, torch.float32, "sin").data_ptr(), int(interleaved), _stream()), "tribe_rotary_fwd")
+    return qkv
+
+
+def attention(qkv: torch.Tensor, B: int, T: int, heads: int, dim_head: int, scale: float) -> torch.Tensor:
+    _cuda(qkv, torch.bfloat16, "qkv")
+    if qkv.numel() != B * T * 3 * heads * dim_head:
+        raise ValueError("attention: qkv has the wrong number of elements")
+    out = torch.empty(B * T, heads * dim_head, dtype=torch.bfloat16, device=qkv.device)
+    nbytes = lib().tribe_attention_workspace_bytes(B, T, heads, dim_head)
+    ws = workspace(nbytes, qkv.device)
+    check(lib().tribe_attention_fwd(qkv.data_ptr(), B, T, heads, dim_head, scale, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "tribe_attention_fwd")
+    return out
+
+
+class EncoderPack:
+    """Device-resident bf16 weights + f32 vectors of one x_transformers-style encoder, laid out for
+    tribe_encoder_fwd.  Built from (and kept alive next to) the fp32 master parameters."""
+
+    def __init__(self, dim: int, depth: int, heads: int, dim_head: int, ff_inner: int, rot_dim: int, rotary_interleaved: bool,
+                 norm_gain_scale: float, norm_eps: float):
+        self.dim, self.depth, self.heads, self.dim_head, self.ff_inner = dim, depth, heads, dim_head, ff_inner
+        self.rot_dim, self.rotary_interleaved = rot_dim, rotary_interleaved
+        self.norm_gain_scale, self.norm_eps = norm_gain_scale, norm_eps
+        self.layers = (EncoderLayer * max(depth, 1))()
+        self.keep: list[torch.Tensor] = []  # owns every tensor the pointer table refers to
+        self.final_norm_g: torch.Tensor | None = None
+        self._tabs: dict[tuple[int, int], tuple[torch.Tensor, torch.Tensor]] = {}
+        self.inv_freq: torch.Tensor | None = None
+
+    def tables(self, T: int, device: torch.device) -> tuple[torch.Tensor | None, torch.Tensor | None]:
+        if self.rot_dim == 0:
+            return None, None
+        key = (T, device.index or 0)
+        if key not in self._tabs:
+            t = torch.arange(T, device=device, dtype=torch.float32)
+            freqs = torch.einsum("i,j->ij", t, self.inv_freq.to(device=device, dtype=torch.float32))
+            self._tabs[key] = (freqs.cos().contiguous(), freqs.sin().contiguous())
+        return self._tabs[key]
+
+
+def encoder_fwd(x: torch.Tensor, pack: EncoderPack, B: int, T: int, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """x f32 [B*T, dim] is consumed (updated in place); returns final-normed y [B*T, dim]."""
+    _cuda(x, torch.float32, "x")
+    if x.shape != (B * T, pack.dim):
+        raise ValueError(f"encoder_fwd: x must be [{B * T}, {pack.dim}], got {tuple(x.shape)}")
+    cos, sin = pack.tables(T, x.device)
+    d = EncoderDesc()
+    d.B, d.T = B, T
+    d.dim, d.depth, d.heads, d.dim_head, d.ff_inner = pack.dim, pack.depth, pack.heads, pack.dim_head, pack.ff_inner
+    d.rot_dim, d.rotary_interleaved = pack.rot_dim, int(pack.rotary_interleaved)
+    d.norm_gain_scale, d.norm_eps = pack.norm_gain_scale, pack.norm_eps
+    d.layers_host = C.cast(pack.layers, C.POINTER(EncoderLayer))
+    d.final_norm_g = pack.final_norm_g.data_ptr()
+    d.cos_tab, d.sin_tab = _p(cos), _p(sin)
+    y = torch.empty(B * T, pack.dim, dtype=out_dtype, device=x.device)
+    nbytes = lib().tribe_encoder_workspace_bytes(C.byref(d))
+    ws = workspace(nbytes, x.device)
+    check(lib().tribe_encoder_fwd(C.byref(d), x.data_ptr(), y.data_ptr(), _DT[out_dtype], ws.data_ptr(), ws.numel(), _stream()),
+          "tribe_encoder_fwd")
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# voxel head, pool, losses
+# --------------------------------------------------------------------------------------
+def voxel_head(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | None, subjects: torch.Tensor, V: int) -> torch.Tensor:
+    """x bf16 [B, T, C_pad]; returns f32 [B, V, T] (SubjectLayers.forward, common.py:45-67)."""
+    _cuda(x, torch.bfloat16, "x")
+    _cuda(w_packed, torch.bfloat16, "w_packed")
+    _cuda(subjects, torch.int64, "subjects")
+    B, T, C_pad = x.shape
+    S, V_pad, C_pad2 = w_packed.shape
+    if C_pad != C_pad2 or subjects.numel() != B:
+        raise ValueError(f"voxel_head: x {tuple(x.shape)} / weights {tuple(w_packed.shape)} / subjects {tuple(subjects.shape)} mismatch")
+    y = torch.empty(B, V, T, dtype=torch.float32, device=x.device)
+    check(lib().tribe_voxel_head_fwd(x.data_ptr(), B, T, C_pad, w_packed.data_ptr(), S, V, V_pad, _p(bias), subjects.data_ptr(),
+                                     y.data_ptr(), _stream()), "tribe_voxel_head_fwd")
+    return y
+
+
+def adaptive_avg_pool(x: torch.Tensor, t_out: int) -> torch.Tensor:
+    _cuda(x, torch.float32, "x")
+    t_in = x.shape[-1]
+    rows = x.numel() // t_in
+    y = torch.empty(*x.shape[:-1], t_out, dtype=torch.float32, device=x.device)
+    check(lib().tribe_adaptive_avg_pool_fwd(x.data_ptr(), rows, t_in, y.data_ptr(), t_out, _stream()), "tribe_adaptive_avg_pool_fwd")
+    return y
+
+
+def mse(pred: torch.Tensor, true: torch.Tensor) -> torch.Tensor:
+    _cuda(pred, torch.float32, "pred")
+    _cuda(true, torch.float32, "true")
+    if pred.shape != true.shape:
+        raise ValueError(f"mse: shape mismatch {tuple(pred.shape)} vs {tuple(true.shape)}")
+    n = pred.numel()
+    out = torch.empty((), dtype=torch.float32, device=pred.device)
+    ws = workspace(lib().tribe_mse_workspace_bytes(n), pred.device, "loss")
+    check(lib().tribe_mse_fwd(pred.data_ptr(), true.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "tribe_mse_fwd")
+    return out
+
+
+def _bvt_strides(pred: torch.Tensor, true: torch.Tensor, what: str) -> tuple[int, int, int, int, int, int]:
+    """Accept any strided 3-D [B, V, T] view (e.g. the transpose of a '(b t) d' matrix) -- no copy is made."""
+    if pred.shape != true.shape or pred.ndim != 3:
+        raise ValueError(f"{what}: expected equal [B, V, T] shapes, got {tuple(pred.shape)} / {tuple(true.shape)}")
+    if pred.stride() != true.stride():
+        raise ValueError(f"{what}: pred and true must share strides, got {pred.stride()} / {true.stride()}")
+    B, V, T = pred.shape
+    sb, sv, st = pred.stride()
+    return B, V, T, sb, sv, st
+
+
+def pearson_stats_update(stats: torch.Tensor, pred: torch.Tensor, true: torch.Tensor, group: torch.Tensor | None = None) -> None:
+    """stats f64 [G, V, 6] += sufficient statistics of pred/true [B, V, T]; group int64 [B] or None."""
+    _cuda(stats, torch.float64, "stats")
+    _cuda(pred, torch.float32, "pred", contiguous=False)
+    _cuda(true, torch.float32, "true", contiguous=False)
+    B, V, T, sb, sv, st = _bvt_strides(pred, true, "pearson_stats_update")
+    G = stats.shape[0]
+    if stats.shape != (G, V, 6):
+        raise ValueError(f"pearson_stats_update: stats must be [G, {V}, 6], got {tuple(stats.shape)}")
+    if group is not None:
+        _cuda(group, torch.int64, "group")
+        if group.numel() != B:
+            raise ValueError("pearson_stats_update: group must have B entries")
+    check(lib().tribe_pearson_stats_update(pred.data_ptr(), true.data_ptr(), B, V, T, sb, sv, st, _p(group), G, stats.data_ptr(),
+                                           _stream()), "tribe_pearson_stats_update")
+
+
+def pearson_from_stats(stats: torch.Tensor) -> torch.Tensor:
+    _cuda(stats, torch.float64, "stats")
+    G, V, _ = stats.shape
+    r = torch.empty(G, V, dtype=torch.float32, device=stats.device)
+    check(lib().tribe_pearson_from_stats(stats.data_ptr(), G, V, r.data_ptr(), _stream()), "tribe_pearson_from_stats")
+    return r
+
+
+def pearson_loss(pred: torch.Tensor, true: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
+    """PearsonLoss over the '(b t) d' view of [B, V, T] tensors (losses.py:17-42); any strided view is accepted."""
+    _cuda(pred, torch.float32, "pred", contiguous=False)
+    _cuda(true, torch.float32, "true", contiguous=False)
+    if reduction not in ("mean", "sum"):
+        raise ValueError(f"Invalid reduction: {reduction}")
+    B, V, T, sb, sv, st = _bvt_strides(pred, true, "pearson_loss")
+    out = torch.empty((), dtype=torch.float32, device=pred.device)
+    ws = workspace(lib().tribe_pearson_loss_workspace_bytes(V), pred.device, "loss")
+    check(lib().tribe_pearson_loss_fwd(pred.data_ptr(), true.data_ptr(), B, V, T, sb, sv, st, int(reduction == "sum"),
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "tribe_pearson_loss_fwd")
+    return out
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]
+_ = tp

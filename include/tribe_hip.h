@@ -1,0 +1,189 @@
+/*
+ * tribe_hip.h -- C ABI of libtribe_hip.so: the MI355X (gfx950) native trimodal
+ * fMRI-encode hot path of TRIBE (vovw/algonauts-2025).
+ *
+ * This is the drop-in boundary: plain pointers and sizes only, no torch types.
+ * Every entry point below replaces one piece of the reference's Python/PyTorch
+ * hot path; the reference line range it replaces is cited (paths relative to
+ * the reference checkout).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless a name ends in _host.
+ *  - The caller owns every buffer including the workspace; the library never
+ *    allocates or frees device memory and keeps no pointer past return.
+ *  - Every call is asynchronous on the `hipStream_t` passed as `void* stream`
+ *    (torch: torch.cuda.current_stream().cuda_stream).
+ *  - Return value: 0 = OK; < 0 = argument / shape / alignment error (message
+ *    via tribe_last_error()); > 0 = hipError_t from the launch.  No exception
+ *    crosses the ABI.
+ *  - "bf16" buffers are uint16_t bit patterns (round-to-nearest-even from f32).
+ *  - Row-major everywhere; "ld*" are leading dimensions in ELEMENTS.
+ */
+#ifndef TRIBE_HIP_H
+#define TRIBE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRIBE_ABI_VERSION 1
+
+enum tribe_dtype { TRIBE_F32 = 0, TRIBE_BF16 = 1, TRIBE_F64 = 2 };
+enum tribe_act { TRIBE_ACT_NONE = 0, TRIBE_ACT_GELU = 1 };
+enum tribe_bias_mode { TRIBE_BIAS_NONE = 0, TRIBE_BIAS_COL = 1, TRIBE_BIAS_ROW = 2 };
+
+int tribe_version(void);
+/* thread-local, valid until the next failing call on this thread */
+const char* tribe_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Generic MFMA GEMM (the workhorse every dense contraction below lowers to)
+ *   C[b1][b0][m][n] = epi( alpha * sum_k A[b1][b0][m][k] * B[b1][b0][n][k] )
+ * A, B bf16 with K contiguous ("NT" form == nn.Linear's [out,in] weights).
+ * K must be a multiple of 64 (callers zero-pad K); M, N arbitrary.
+ * epi(v) = act(v + bias) + res * res_scale + rowadd[m % period] + gadd[gidx[m / div]]
+ * Replaces torch.nn.functional.linear / torch.einsum / torch.bmm call sites of
+ * model.py:157, common.py:64 and the x_transformers Attention / FeedForward.
+ * ------------------------------------------------------------------------- */
+typedef struct tribe_gemm_desc {
+  int64_t M, N, K;
+  int64_t batch1, batch0; /* grid z = batch1 * batch0; b1 = z / batch0, b0 = z % batch0 */
+  const void* A; int64_t lda, sA1, sA0;
+  const void* B; int64_t ldb, sB1, sB0;
+  void* C; int64_t ldc, sC1, sC0;
+  int32_t c_dtype;         /* TRIBE_F32 or TRIBE_BF16 */
+  float alpha;
+  const int64_t* gather1;  /* optional [batch1]: index replacing b1 for A (gather_a) and bias (gather_bias) */
+  int32_t gather_a, gather_bias;
+  const float* bias; int32_t bias_mode; int64_t sBias1; /* f32; per-col [N] or per-row [M]; + b1' * sBias1 */
+  int32_t act;
+  const float* res; int64_t ldres, sRes1, sRes0; /* f32 residual, may alias C when c_dtype == F32 */
+  const float* res_scale;  /* f32 [N] or NULL (= 1) */
+  const float* rowadd; int64_t ld_rowadd, rowadd_period; /* + rowadd[(m % period)][n] */
+  const float* gadd; const int64_t* gadd_index; int64_t gadd_div, ld_gadd; /* + gadd[gadd_index[m / div]][n] */
+} tribe_gemm_desc;
+
+int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Packing (one-time per parameter version; fp32 master weights stay in torch)
+ * ------------------------------------------------------------------------- */
+/* f32 [rows, cols] (ld = ld_src) -> bf16 [rows_pad, cols_pad], zero padded */
+int tribe_pack_weight_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld_src,
+                           uint16_t* dst, int64_t rows_pad, int64_t cols_pad, void* stream);
+/* SubjectLayers weights (common.py:26) f32 [S, C, V] -> bf16 [S, V_pad, C_pad] (transposed, zero padded) */
+int tribe_pack_subject_weights(const float* w, int64_t S, int64_t C, int64_t V,
+                               uint16_t* dst, int64_t V_pad, int64_t C_pad, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a3: FmriEncoder.aggregate_features prologue (model.py:146-155)
+ *   feat [B, L, D, T] (f32 / bf16 / f64) -> bf16 [B*T, K_pad]
+ *   layer_mean == 0: "b l d t -> b t (l d)"; == 1: mean over l then "b d t -> b t d"
+ * ------------------------------------------------------------------------- */
+int tribe_pack_features(const void* feat, int32_t dtype, int64_t B, int64_t L, int64_t D, int64_t T,
+                        int32_t layer_mean, uint16_t* dst, int64_t K_pad, void* stream);
+
+/* a3/a4: one modality's projector nn.Linear (model.py:157) writing its column
+ * slice of the fused [B*T, hidden] f32 stream (torch.cat, model.py:161-162) and
+ * adding time_pos_embed[:, :T] (+ subject_embed[subject_id]) (model.py:169-172).
+ * accumulate != 0 adds into x (feature_aggregation == "sum", model.py:163-164). */
+int tribe_projector_fwd(const uint16_t* feat_packed, int64_t BT, int64_t T, int64_t K_pad,
+                        const uint16_t* w_packed /*[N_out, K_pad]*/, const float* bias /*[N_out]*/, int64_t N_out,
+                        float* x, int64_t hidden, int64_t col0, int32_t accumulate,
+                        const float* pos_embed /*[>=T, hidden] or NULL*/,
+                        const float* subj_embed /*[S, hidden] or NULL*/, const int64_t* subject_id /*[B]*/,
+                        void* stream);
+/* zero-filled block for a modality without projector (model.py:143-144) incl. the pos/subject adds */
+int tribe_projector_zero_fwd(int64_t BT, int64_t T, int64_t N_out, float* x, int64_t hidden, int64_t col0,
+                             const float* pos_embed, const float* subj_embed, const int64_t* subject_id,
+                             void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a6: x_transformers.Encoder (called at model.py:173)
+ * ------------------------------------------------------------------------- */
+/* ScaleNorm: y = x / max(||x||_2, eps) * gain_scale * g[0]  (g read on device) */
+int tribe_scalenorm_fwd(const float* x, int64_t rows, int64_t dim, const float* g, float gain_scale, float eps,
+                        void* y, int32_t y_dtype, void* stream);
+/* partial rotary on q and k inside a fused qkv buffer [rows, 3*heads*dim_head] bf16, in place.
+ * cos/sin: f32 [T, rot_dim/2]; interleaved != 0 pairs (2i,2i+1), else (i, i+rot_dim/2). */
+int tribe_rotary_fwd(uint16_t* qkv, int64_t rows, int64_t T, int32_t heads, int32_t dim_head, int32_t rot_dim,
+                     const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream);
+/* softmax(q k^T * scale) v for all (batch, head); qkv as above; out bf16 [rows, heads*dim_head] */
+size_t tribe_attention_workspace_bytes(int64_t B, int64_t T, int32_t heads, int32_t dim_head);
+int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, int32_t heads, int32_t dim_head, float scale,
+                        uint16_t* out, void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct tribe_encoder_layer {
+  /* attention block */
+  const float* attn_norm_g;       /* [1] */
+  const uint16_t* w_qkv;          /* bf16 [3*inner, dim]  rows: q | k | v */
+  const uint16_t* w_out;          /* bf16 [dim, inner] */
+  const float* attn_res_scale;    /* [dim] or NULL */
+  /* feed-forward block */
+  const float* ff_norm_g;         /* [1] */
+  const uint16_t* w_ff1;          /* bf16 [ff_inner, dim] */
+  const float* b_ff1;             /* [ff_inner] */
+  const uint16_t* w_ff2;          /* bf16 [dim, ff_inner] */
+  const float* b_ff2;             /* [dim] */
+  const float* ff_res_scale;      /* [dim] or NULL */
+} tribe_encoder_layer;
+
+typedef struct tribe_encoder_desc {
+  int64_t B, T;
+  int32_t dim, depth, heads, dim_head, ff_inner, rot_dim, rotary_interleaved;
+  float norm_gain_scale, norm_eps;   /* ScaleNorm flavour */
+  const tribe_encoder_layer* layers_host; /* HOST array [depth] of device pointers */
+  const float* final_norm_g;         /* [1] */
+  const float* cos_tab; const float* sin_tab; /* f32 [T, rot_dim/2] or NULL when rot_dim == 0 */
+} tribe_encoder_desc;
+
+size_t tribe_encoder_workspace_bytes(const tribe_encoder_desc* d);
+/* x: f32 [B*T, dim] residual stream, updated in place; y: final-normed output (bf16 or f32) [B*T, dim] */
+int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y, int32_t y_dtype,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a7 + a8: SubjectLayers.forward (common.py:45-67) and AdaptiveAvgPool1d (model.py:119-120)
+ *   y[b, v, t] = sum_c x[b, t, c] * w[subj[b], c, v] + bias[subj[b], v]
+ * x bf16 [B, T, C_pad]; w_packed from tribe_pack_subject_weights; y f32 [B, V, T].
+ * subjects: int64 [B] device; every entry must be < S (checked by the host wrapper,
+ * mirroring the assert at common.py:53-55).
+ * ------------------------------------------------------------------------- */
+int tribe_voxel_head_fwd(const uint16_t* x, int64_t B, int64_t T, int64_t C_pad,
+                         const uint16_t* w_packed, int64_t S, int64_t V, int64_t V_pad,
+                         const float* bias /*[S, V] or NULL*/, const int64_t* subjects,
+                         float* y, void* stream);
+int tribe_adaptive_avg_pool_fwd(const float* x, int64_t rows, int64_t T_in, float* y, int64_t T_out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a10-a14: loss and per-voxel Pearson on [B, V, T'] predictions / targets
+ * (pl_module.py:54-56 flattens "b d t -> (b t) d"; the reductions below are
+ * order-independent so the flatten is never materialised).
+ * ------------------------------------------------------------------------- */
+/* nn.MSELoss(): out[0] = mean((pred-true)^2) over all elements (f32 scalar) */
+int tribe_mse_fwd(const float* pred, const float* truth, int64_t n, float* out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+size_t tribe_mse_workspace_bytes(int64_t n);
+/* accumulate f64 sufficient statistics per (group, voxel):
+ *   stats[g][v][0..5] += {sum x, sum y, sum x^2, sum y^2, sum xy, count}
+ * x = pred, y = true, over rows b with group[b] == g (group == NULL: all rows -> g = 0) and all t.
+ * metrics/base.py:26-29,52-78 (MultidimPearsonCorrCoef / GroupedMetric) and main.py:459-477. */
+int tribe_pearson_stats_update(const float* pred, const float* truth, int64_t B, int64_t V, int64_t T,
+                               int64_t sb, int64_t sv, int64_t st, /* element strides of b, v, t ([B,V,T] contiguous: V*T, T, 1) */
+                               const int64_t* group, int64_t n_groups, double* stats, void* stream);
+/* r[g][v] from stats (f32 out); count < 2 or zero variance -> NaN (scipy/torchmetrics behaviour) */
+int tribe_pearson_from_stats(const double* stats, int64_t n_groups, int64_t V, float* r, void* stream);
+/* PearsonLoss (losses.py:17-42) over the flattened [(B T'), V] view: out[0] = mean|sum_v (1 - r_v), eps 1e-8 */
+int tribe_pearson_loss_fwd(const float* pred, const float* truth, int64_t B, int64_t V, int64_t T,
+                           int64_t sb, int64_t sv, int64_t st,
+                           int32_t reduction_sum, float* out, void* workspace, size_t workspace_bytes, void* stream);
+size_t tribe_pearson_loss_workspace_bytes(int64_t V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIBE_HIP_H */

@@ -1,0 +1,153 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/tribe_hip.h declares,
+the ctypes structs match the C layout, and the host-side mirror keeps the reference's plugin
+surface (names, config fields, state_dict keys, error behaviour).  No compute call is made."""
+
+import ctypes
+import re
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "tribe_hip.h"
+
+
+def _declared_symbols() -> list[str]:
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(tribe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tribe_hip import _lib
+
+    handle = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/tribe_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(declared)
+    assert handle.tribe_version() == 1
+
+
+def test_ctypes_struct_layout_matches_c(tmp_path):
+    """sizeof / offsetof from a C translation unit vs the ctypes mirrors."""
+    from tribe_hip import _lib
+
+    src = tmp_path / "layout.c"
+    src.write_text(textwrap.dedent(f"""
+        #include <stdio.h>
+        #include <stddef.h>
+        #include "{HEADER}"
+        int main(void) {{
+          printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(tribe_gemm_desc), offsetof(tribe_gemm_desc, alpha),
+                 offsetof(tribe_gemm_desc, ld_gadd), sizeof(tribe_encoder_layer), sizeof(tribe_encoder_desc),
+                 offsetof(tribe_encoder_desc, layers_host));
+          return 0;
+        }}"""))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(_lib.GemmDesc), _lib.GemmDesc.alpha.offset, _lib.GemmDesc.ld_gadd.offset,
+            ctypes.sizeof(_lib.EncoderLayer), ctypes.sizeof(_lib.EncoderDesc), _lib.EncoderDesc.layers_host.offset]
+    assert got == want
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    """Negative return + message for malformed descriptors (validated before any launch)."""
+    from tribe_hip import _lib
+
+    handle = _lib.lib()
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch0 = 8, 8, 48, 1, 1  # K not a multiple of 64
+    rc = handle.tribe_gemm_bf16(ctypes.byref(d), None)
+    assert rc < 0 and b"multiple of 64" in handle.tribe_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "tribe_gemm_bf16")
+    assert handle.tribe_scalenorm_fwd(None, 4, 8, None, 1.0, 1e-5, None, 0, None) < 0
+    assert handle.tribe_attention_workspace_bytes(4, 1024, 8, 384) > 0
+
+
+def test_host_surface_matches_reference_names():
+    from algonauts2025.model import FmriEncoder, FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from data_utils.dataloader import SegmentData
+    from modeling_utils.losses import PearsonLossConfig, TorchLossConfig
+    from modeling_utils.models import MlpConfig, SubjectLayers, TransformerEncoderConfig
+    from oracle import tribe_ref
+
+    cfg = FmriEncoderConfig(n_subjects=4)
+    for field, default in dict(name="FmriEncoder", feature_aggregation="cat", layer_aggregation="cat", subject_embedding=False,
+                               modality_dropout=0.0, contrastive_enabled=False, contrastive_modalities=["video"],
+                               contrastive_weight=0.1, contrastive_temperature=0.07).items():
+        assert getattr(cfg, field) == default  # model.py:20-33
+    with pytest.raises(Exception):
+        FmriEncoderConfig(n_subjects=4, bogus=1)  # extra="forbid"
+    fdims = {"text": (2, 24), "audio": None, "video": (2, 12)}
+    small = FmriEncoderConfig(n_subjects=4, hidden=768, depth=2, heads=4, subject_embedding=True, contrastive_enabled=True)
+    m = small.build(fdims, n_outputs=37, n_output_timesteps=5)
+    assert isinstance(m, FmriEncoder)
+    ref = tribe_ref.FmriEncoderRef(fdims, 37, 5, 4, subject_embedding=True, contrastive_modalities=["video"],
+                                   dims=tribe_ref.EncoderDims(hidden=768, depth=2, heads=4))
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert "audio" not in m.projectors and set(m.contrastive_heads) == {"video"}
+    # transformer.py:46-53
+    with pytest.raises(ValueError):
+        TransformerEncoderConfig(heads=7).build(dim=768)
+    with pytest.raises(ValueError):
+        TransformerEncoderConfig(heads=4).build(dim=128)
+    assert isinstance(MlpConfig(norm_layer="layer", activation_layer="gelu").build(6144, 1024), torch.nn.Linear)  # common.py:124-128
+    sl = SubjectLayers(48, 13, 4, bias=True)
+    assert tuple(sl.weights.shape) == (4, 48, 13) and tuple(sl.bias.shape) == (4, 13) and repr(sl) == "SubjectLayers(48, 13, 4)"
+    with pytest.raises(ValueError):
+        SubjectLayers(4, 5, 2, init_id=True)
+    # dataloader.py:33-53
+    with pytest.raises(ValueError):
+        SegmentData(data={}, segments=[])
+    with pytest.raises(RuntimeError):
+        SegmentData(data={"x": torch.zeros(2, 3)}, segments=[None])
+    sd = SegmentData(data={"x": torch.zeros(2, 3)}, segments=[None, None])
+    with pytest.raises(RuntimeError):
+        sd["x"]
+    assert sd.to("cpu").data["x"].shape == (2, 3)
+    assert type(TorchLossConfig(name="MSELoss").build()).__name__ == "MSELoss"
+    assert type(TorchLossConfig(name="HuberLoss").build()).__module__.startswith("torch.nn")
+    assert PearsonLossConfig(reduction="sum").build().reduction == "sum"
+    bm = BrainModule(m, TorchLossConfig(name="MSELoss").build(), None, {})
+    for name in ("forward", "_run_step", "training_step", "validation_step", "test_step", "on_validation_epoch_end"):
+        assert hasattr(bm, name)
+
+
+def test_hot_path_refuses_cpu_tensors():
+    """No CPU fallback: the product path raises when handed host tensors."""
+    from algonauts2025.model import FmriEncoderConfig
+    from tribe_hip import TribeHipError
+
+    m = FmriEncoderConfig(n_subjects=2, hidden=768, depth=1, heads=4).build({"text": (1, 8)}, 5, 3)
+    with pytest.raises(TribeHipError):
+        m({"text": torch.zeros(1, 1, 8, 4), "subject_id": torch.zeros(1, 1, dtype=torch.long)})
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); from tribe_hip import _lib; _lib.lib()" % str(ROOT / "algonauts-2025_amd"))
+    env = {"TRIBE_HIP_LIB": str(tmp_path / "nope.so"), "PATH": "/usr/bin:/bin"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU / PyTorch fallback" in r.stderr
+
+
+def test_layer_grouping_matches_oracle():
+    import numpy as np
+
+    from data_utils.features import aggregate_layers
+    from oracle import tribe_ref
+
+    lat = np.random.default_rng(0).normal(size=(29, 7)).astype(np.float32)
+    for layers in ([0.5, 0.75, 1.0], [1.0], [0, 0.2, 0.4, 0.6, 0.8, 1.0], [0.5, 1.0]):
+        for agg in (None, "group_mean"):
+            np.testing.assert_allclose(aggregate_layers(lat, layers, agg), tribe_ref.aggregate_layers(lat, layers, agg))
+    with pytest.raises(ValueError):
+        aggregate_layers(lat, [0.5, 1.0], "bogus")

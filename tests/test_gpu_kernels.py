@@ -1,0 +1,258 @@
+"""GPU parity of every HIP kernel / C-ABI entry point against the CPU oracle (or plain fp32 torch
+on the host for a bare GEMM), on seeded inputs.  Tolerances are stated per test: the MFMA path
+multiplies bf16-rounded operands exactly and accumulates in fp32, so against an fp32 reference fed
+the SAME bf16-rounded operands only accumulation order (~1e-6 rel) and, for bf16 outputs, one
+final rounding (2^-9 rel) remain."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tribe_ref, xt_encoder  # noqa: E402
+
+
+def bf(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tribe_hip import ops as _ops
+
+    return _ops
+
+
+def _dev(x):
+    return x.cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric B catches a swapped C/D register->(row, col) map."""
+    K = 128
+    a = torch.eye(K)
+    b = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) % 251 - 125  # exactly representable in bf16
+    out = ops.gemm_nt(_dev(a).bfloat16(), _dev(b).bfloat16())
+    torch.testing.assert_close(out.cpu(), b.t().contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1000, 192), (1000, 298, 3072), (4, 5, 64), (129, 129, 64)])
+def test_gemm_shapes(ops, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g))
+    out = ops.gemm_nt(_dev(a).bfloat16(), _dev(b).bfloat16())
+    ref = a.double() @ b.double().t()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-4 * K**0.5)
+
+
+def test_gemm_epilogues(ops):
+    g = torch.Generator().manual_seed(3)
+    M, N, K, T = 96, 160, 128, 32
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / K**0.5)
+    bias, rs = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    res = torch.randn(M, N, generator=g)
+    rowadd = torch.randn(T, N, generator=g)
+    gadd, gidx = torch.randn(5, N, generator=g), torch.tensor([4, 0, 2])
+    A, B = _dev(a).bfloat16(), _dev(b).bfloat16()
+    base = a @ b.t()
+    # bias + gelu, bf16 out  (one bf16 rounding: rel 2^-8 worst case)
+    out = ops.gemm_nt(A, B, bias=_dev(bias), act="gelu", out_dtype=torch.bfloat16)
+    torch.testing.assert_close(out.float().cpu(), torch.nn.functional.gelu(base + bias), rtol=2**-7, atol=1e-3)
+    # residual * scale + bias, in place on the residual buffer
+    x = _dev(res.clone())
+    ops.gemm_nt(A, B, bias=_dev(bias), res=x, res_scale=_dev(rs), out=x)
+    torch.testing.assert_close(x.cpu(), base + bias + res * rs, rtol=1e-5, atol=1e-4)
+    # alpha, row bias, rowadd (period T) and gathered add (div T)
+    rb = torch.randn(M, generator=g)
+    out = ops.gemm_nt(A, B, alpha=0.25, bias=_dev(rb), bias_row=True, rowadd=_dev(rowadd), rowadd_period=T, gadd=_dev(gadd),
+                      gadd_index=_dev(gidx), gadd_div=T)
+    m = torch.arange(M)
+    want = 0.25 * base + rb[:, None] + rowadd[m % T] + gadd[gidx[m // T]]
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=1e-4)
+    # batched
+    a3, b3 = bf(torch.randn(3, 70, 64, generator=g)), bf(torch.randn(3, 40, 64, generator=g))
+    out = ops.gemm_nt(_dev(a3).bfloat16(), _dev(b3).bfloat16())
+    torch.testing.assert_close(out.cpu(), torch.einsum("zmk,znk->zmn", a3, b3), rtol=1e-5, atol=1e-4)
+    with pytest.raises(ValueError):
+        ops.gemm_nt(_dev(torch.zeros(8, 48)).bfloat16(), _dev(torch.zeros(8, 48)).bfloat16())  # K % 64
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64])
+@pytest.mark.parametrize("layer_mean", [False, True])
+def test_pack_features(ops, dtype, layer_mean):
+    g = torch.Generator().manual_seed(5)
+    B, L, D, T = 3, 2, 37, 70
+    feat = torch.randn(B, L, D, T, generator=g).to(dtype)
+    out = ops.pack_features(_dev(feat), layer_mean).float().cpu()
+    want = tribe_ref.prepare_modality(feat, "mean" if layer_mean else "cat")  # [B, T, K] fp32 (model.py:146-155)
+    K = want.shape[-1]
+    assert out.shape == (B * T, (K + 63) // 64 * 64)
+    torch.testing.assert_close(out[:, :K], bf(want.reshape(B * T, K)), rtol=0, atol=0)
+    assert out[:, K:].abs().max() == 0
+    out3 = ops.pack_features(_dev(feat[:, 0].contiguous()), False).float().cpu()  # [B, D, T] input (model.py:148-149)
+    torch.testing.assert_close(out3[:, :D], bf(feat[:, 0].float().transpose(1, 2).reshape(B * T, D)), rtol=0, atol=0)
+
+
+def test_pack_weights(ops):
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(50, 100, generator=g)
+    p = ops.pack_weight(_dev(w)).float().cpu()
+    assert p.shape == (50, 128)
+    torch.testing.assert_close(p[:, :100], bf(w), rtol=0, atol=0)
+    assert p[:, 100:].abs().max() == 0
+    sw = torch.randn(3, 70, 45, generator=g)
+    ps = ops.pack_subject_weights(_dev(sw)).float().cpu()
+    assert ps.shape == (3, 128, 128)
+    torch.testing.assert_close(ps[:, :45, :70], bf(sw.transpose(1, 2)), rtol=0, atol=0)
+    assert ps[:, 45:].abs().max() == 0 and ps[:, :, 70:].abs().max() == 0
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_scalenorm(ops, legacy):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(37, 768, generator=g) * 3
+    x[5] = 0  # eps path
+    ref = xt_encoder.ScaleNorm(768, legacy=legacy)
+    with torch.no_grad():
+        ref.g.mul_(1.3)
+        want = ref(x)
+    gain_scale = 1.0 if legacy else 768**0.5
+    y = ops.scalenorm(_dev(x), _dev(ref.g.detach()), gain_scale, ref.eps, torch.float32)
+    torch.testing.assert_close(y.cpu(), want, rtol=1e-5, atol=1e-6)
+    yb = ops.scalenorm(_dev(x), _dev(ref.g.detach()), gain_scale, ref.eps, torch.bfloat16)
+    torch.testing.assert_close(yb.float().cpu(), want, rtol=2**-8, atol=1e-6)
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_rotary(ops, interleaved):
+    g = torch.Generator().manual_seed(8)
+    B, T, h, d = 2, 19, 4, 192
+    rot = max(d // 2, 32)
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g))
+    rope = xt_encoder.RotaryEmbedding(rot, interleaved=interleaved)
+    freqs = rope(T)
+    half = torch.einsum("i,j->ij", torch.arange(T).float(), rope.inv_freq)
+    out = ops.rotary_(_dev(qkv).bfloat16(), T, h, d, rot, _dev(half.cos().contiguous()), _dev(half.sin().contiguous()),
+                      interleaved).float().cpu()
+    q, k, v = qkv.view(B, T, 3, h, d).unbind(2)
+    want_q = xt_encoder.apply_rotary_pos_emb(q.transpose(1, 2), freqs, interleaved).transpose(1, 2)
+    want_k = xt_encoder.apply_rotary_pos_emb(k.transpose(1, 2), freqs, interleaved).transpose(1, 2)
+    got = out.view(B, T, 3, h, d)
+    torch.testing.assert_close(got[:, :, 0], want_q, rtol=2**-8, atol=2**-8)
+    torch.testing.assert_close(got[:, :, 1], want_k, rtol=2**-8, atol=2**-8)
+    torch.testing.assert_close(got[:, :, 2], v, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("B,T,h,d", [(2, 70, 4, 64), (1, 298, 2, 192), (3, 128, 8, 384)])
+def test_attention(ops, B, T, h, d):
+    g = torch.Generator().manual_seed(9)
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g))
+    scale = d**-0.5
+    out = ops.attention(_dev(qkv).bfloat16(), B, T, h, d, scale).float().cpu()
+    q, k, v = (t.transpose(1, 2) for t in qkv.view(B, T, 3, h, d).unbind(2))
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    want = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).transpose(1, 2).reshape(B * T, h * d)
+    # P and the output are rounded to bf16 once each: 2 * 2^-9 relative on O(1/sqrt(T))-sized values
+    torch.testing.assert_close(out, want, rtol=2**-6, atol=3e-3)
+
+
+@pytest.mark.parametrize("interleaved,legacy", [(True, False), (False, True)])
+def test_encoder_vs_oracle(ops, interleaved, legacy):
+    """2-layer dim-768 encoder: HIP (bf16 operands, fp32 accumulate / residual) vs the fp32 oracle."""
+    from modeling_utils.models.transformer import TransformerEncoderConfig
+
+    torch.manual_seed(0)
+    dim, depth, heads, B, T = 768, 2, 4, 2, 50
+    ref = xt_encoder.Encoder(dim=dim, depth=depth, heads=heads, attn_dim_head=dim // heads, rotary_interleaved=interleaved,
+                             legacy_scalenorm=legacy).eval()
+    with torch.no_grad():
+        tribe_ref.fill_params_(ref, seed=1)
+    enc = TransformerEncoderConfig(depth=depth, heads=heads, attn_dropout=0.0, rotary_interleaved=interleaved,
+                                   legacy_scalenorm=legacy).build(dim)
+    enc.load_state_dict(ref.state_dict())
+    enc = enc.cuda()
+    x = torch.randn(B, T, dim)
+    with torch.no_grad():
+        want = ref(x)
+    got = enc(_dev(x)).cpu()
+    err = (got - want).norm() / want.norm()
+    assert err < 6e-3, f"relative L2 error {err:.2e}"  # ~2^-9 per bf16 operand rounding, 8 GEMMs + 2 attention products deep
+
+
+def test_voxel_head_golden(ops, golden_dir):
+    """G1 (reference SubjectLayers executed on CPU) vs tribe_voxel_head_fwd through the module API."""
+    from modeling_utils.models import SubjectLayers
+
+    g = np.load(golden_dir / "g1_subject_layers.npz")
+    x, w, b = (torch.from_numpy(g[k]) for k in ("x", "w", "b"))
+    subj = torch.from_numpy(g["subj"])
+    sl = SubjectLayers(48, 13, 4, bias=True)
+    with torch.no_grad():
+        sl.weights.copy_(w)
+        sl.bias.copy_(b)
+    sl = sl.cuda()
+    y = sl(_dev(x), _dev(subj)).cpu()
+    # operands are rounded to bf16 (2^-9 rel each) before an exact 48-term fp32 dot product of O(1) values
+    torch.testing.assert_close(y, torch.from_numpy(g["y"]), rtol=0, atol=3e-2)
+    want_bf = tribe_ref.subject_layers_fwd(bf(x), bf(w), b, subj)
+    torch.testing.assert_close(y, want_bf, rtol=1e-5, atol=1e-5)  # same rounded operands -> fp32-exact
+    with pytest.raises(AssertionError):
+        sl(_dev(x), _dev(subj + 2))  # common.py:53-55
+    sl_nb = SubjectLayers(48, 13, 4, bias=False)
+    with torch.no_grad():
+        sl_nb.weights.copy_(w)
+    y = sl_nb.cuda()(_dev(x), _dev(subj.flatten())).cpu()
+    torch.testing.assert_close(y, tribe_ref.subject_layers_fwd(bf(x), bf(w), None, subj), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("t_in,t_out", [(298, 100), (14, 5), (1024, 1024), (100, 7)])
+def test_adaptive_pool(ops, t_in, t_out):
+    x = torch.randn(3, 11, t_in)
+    torch.testing.assert_close(ops.adaptive_avg_pool(_dev(x), t_out).cpu(), torch.nn.AdaptiveAvgPool1d(t_out)(x), rtol=1e-5, atol=1e-6)
+
+
+def test_losses_and_pearson(ops, golden_dir):
+    from modeling_utils.losses import MSELoss, PearsonLoss
+    from modeling_utils.metrics import GroupedMetric, MultidimPearsonCorrCoef
+
+    g4 = np.load(golden_dir / "g4_pearson_loss.npz")
+    x, y = torch.from_numpy(g4["x"]), torch.from_numpy(g4["y"])
+    np.testing.assert_allclose(PearsonLoss("mean")(_dev(x), _dev(y)).cpu().numpy(), g4["mean"], rtol=1e-5)
+    np.testing.assert_allclose(PearsonLoss("sum")(_dev(x), _dev(y)).cpu().numpy(), g4["sum"], rtol=1e-5)
+    with pytest.raises(ValueError):
+        PearsonLoss("none")(_dev(x), _dev(y))
+    g = torch.Generator().manual_seed(11)
+    B, V, T = 5, 33, 100
+    pred = torch.randn(B, V, T, generator=g)
+    true = 0.3 * pred + torch.randn(B, V, T, generator=g)
+    sid = torch.tensor([[2], [0], [1], [2], [0]])
+    loss, p_flat, t_flat, groups = tribe_ref.run_step(pred, true, sid)
+    np.testing.assert_allclose(MSELoss()(_dev(pred), _dev(true)).cpu().numpy(), loss.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(PearsonLoss().forward_bvt(_dev(pred), _dev(true)).cpu().numpy(),
+                               tribe_ref.pearson_loss(p_flat, t_flat).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(PearsonLoss()(_dev(p_flat), _dev(t_flat)).cpu().numpy(),
+                               tribe_ref.pearson_loss(p_flat, t_flat).numpy(), rtol=1e-5)
+    # streaming metric over two updates vs scipy on the concatenation (main.py:474-477)
+    ref = tribe_ref.scipy_pearson_columns(p_flat.numpy(), t_flat.numpy())
+    metric = MultidimPearsonCorrCoef(num_outputs=V)
+    metric.update(_dev(pred[:2]), _dev(true[:2]))
+    metric.update(_dev(flat := tribe_ref.flatten_bt(pred[2:])), _dev(tribe_ref.flatten_bt(true[2:])))  # [N, V] form
+    np.testing.assert_allclose(metric.per_output()[0].cpu().numpy(), ref, atol=2e-6)
+    np.testing.assert_allclose(float(metric.compute()), ref.mean(), atol=2e-6)
+    _ = flat
+    # grouped by subject (metrics/base.py:52-78): keys in first-seen order, value = mean r of that subject's rows
+    gm = GroupedMetric("MultidimPearsonCorrCoef", {"num_outputs": V})
+    gm.update(_dev(pred), _dev(true), groups=_dev(sid))
+    out = gm.compute()
+    assert list(out.keys()) == ["2", "0", "1"]
+    for key in out:
+        rows = groups.flatten() == int(key)
+        want = tribe_ref.scipy_pearson_columns(p_flat[rows].numpy(), t_flat[rows].numpy()).mean()
+        assert abs(out[key] - want) < 2e-6
+    gm2 = GroupedMetric("MultidimPearsonCorrCoef", {"num_outputs": V})
+    gm2.update(_dev(p_flat), _dev(t_flat), groups=_dev(groups))  # reference calling convention ([N, V] + per-row groups)
+    for key in out:
+        assert abs(gm2.compute()[key] - out[key]) < 1e-6

@@ -1,0 +1,204 @@
+"""GPU parity of the whole encode path (FmriEncoder / BrainModule) against the CPU oracle and the
+golden vectors generated from the reference's own files, plus the BASELINE parity criterion:
+per-voxel Pearson r of GPU predictions equals that of the CPU reference path to 3 decimals."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tribe_ref  # noqa: E402
+
+PEARSON_TOL = 5e-4  # "equal to 3 dp": half a unit of the third decimal
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _cuda_batch(data):
+    from data_utils.dataloader import SegmentData
+
+    B = data["subject_id"].shape[0]
+    return SegmentData(data={k: v.cuda() for k, v in data.items()}, segments=[None] * B)
+
+
+G2_CASES = [(fa, la, v) for fa in ("cat", "sum") for la in ("cat", "mean") for v in ("tri", "one_none", "ndim3")]
+
+
+@pytest.mark.parametrize("fa,la,variant", G2_CASES)
+def test_aggregate_features_golden(golden_dir, fa, la, variant):
+    """G2: the reference's aggregate_features (model.py:125-165) at hidden 3072 vs pack + projector kernels."""
+    from algonauts2025.model import FmriEncoderConfig
+
+    g = np.load(golden_dir / "g2_aggregate_features.npz")
+    fdims = {
+        "tri": {"text": (2, 24), "audio": (2, 8), "video": (2, 12)},
+        "one_none": {"text": (2, 24), "audio": None, "video": (2, 12)},
+        "ndim3": {"text": (1, 24), "audio": (1, 8), "video": (1, 12)},
+    }[variant]
+    m = FmriEncoderConfig(n_subjects=4, feature_aggregation=fa, layer_aggregation=la, depth=0).build(fdims, 7, 3).eval()
+    with torch.no_grad():
+        tribe_ref.fill_params_(m, seed=3)
+    m = m.cuda()
+    data = tribe_ref.synthetic_batch(2, 6, fdims, 4, seed=11)
+    if variant == "ndim3":
+        data = {k: (v[:, 0].contiguous() if v.ndim == 4 else v) for k, v in data.items()}
+    key = f"{fa}_{la}_{variant}"
+    if key + "_raises" in g:
+        with pytest.raises(RuntimeError):
+            m.aggregate_features(_cuda_batch(data))
+        return
+    y = m.aggregate_features(_cuda_batch(data)).cpu()
+    # bf16 operands (2^-9 rel each), K <= 48 terms of O(0.1): abs error well under 5e-3
+    torch.testing.assert_close(y[..., ::8], torch.from_numpy(g[key]), rtol=0, atol=5e-3)
+    np.testing.assert_allclose(y.double().abs().sum().item(), g[key + "_sum"][1], rtol=2e-3)
+
+
+@pytest.mark.parametrize("subj_emb", [False, True])
+def test_full_forward_golden(golden_dir, subj_emb):
+    """G3: reference FmriEncoder.forward glue at full size (3072 x 8 layers, restated encoder) vs the HIP path."""
+    from algonauts2025.model import FmriEncoderConfig
+
+    g = np.load(golden_dir / "g3_forward.npz")
+    fdims = {"text": (2, 24), "audio": (2, 8), "video": (2, 12)}
+    m = FmriEncoderConfig(n_subjects=4, subject_embedding=subj_emb).build(fdims, 37, 5).eval()
+    with torch.no_grad():
+        tribe_ref.fill_params_(m, seed=5)
+    m = m.cuda()
+    data = tribe_ref.synthetic_batch(2, 14, fdims, 4, seed=17)
+    data["subject_id"] = torch.tensor([[1], [3]])
+    tag = "se" if subj_emb else "nose"
+    for pooled in (True, False):
+        got = m(_cuda_batch(data), pool_outputs=pooled).cpu()
+        want = torch.from_numpy(g[f"{'pooled' if pooled else 'unpooled'}_{tag}"])
+        err = (got - want).norm() / want.norm()
+        assert got.shape == want.shape and err < 2e-2, f"relative L2 error {err:.2e}"
+
+
+def _small_pair(fdims, V, Tout, S, **cfg_kw):
+    from algonauts2025.model import FmriEncoderConfig
+
+    dims = tribe_ref.EncoderDims(hidden=768, depth=2, heads=4, rotary_interleaved=cfg_kw.get("rotary_interleaved", True),
+                                 legacy_scalenorm=cfg_kw.get("legacy_scalenorm", False))
+    ref = tribe_ref.FmriEncoderRef(fdims, V, Tout, S, feature_aggregation=cfg_kw.get("feature_aggregation", "cat"),
+                                   layer_aggregation=cfg_kw.get("layer_aggregation", "cat"),
+                                   subject_embedding=cfg_kw.get("subject_embedding", False), dims=dims).eval()
+    with torch.no_grad():
+        tribe_ref.fill_params_(ref, seed=2)
+    m = FmriEncoderConfig(n_subjects=S, hidden=768, depth=2, heads=4, **cfg_kw).build(fdims, V, Tout).eval()
+    m.load_state_dict(ref.state_dict())  # same keys: drop-in state_dict
+    return ref, m.cuda()
+
+
+@pytest.mark.parametrize("cfg_kw", [
+    {}, {"feature_aggregation": "sum"}, {"layer_aggregation": "mean", "subject_embedding": True},
+    {"rotary_interleaved": False, "legacy_scalenorm": True},
+])
+def test_small_model_vs_oracle(cfg_kw):
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    ref, m = _small_pair(fdims, 50, 10, 3, **cfg_kw)
+    data = tribe_ref.synthetic_batch(5, 31, fdims, 3, seed=4)
+    with torch.no_grad():
+        want = ref(data)
+        want_unpooled = ref(data, pool_outputs=False)
+    got = m(_cuda_batch(data)).cpu()
+    assert got.shape == (5, 50, 10)
+    assert (got - want).norm() / want.norm() < 1e-2
+    got_u = m(_cuda_batch(data), pool_outputs=False).cpu()
+    assert (got_u - want_unpooled).norm() / want_unpooled.norm() < 1e-2
+    lat = m.get_brain_latents(_cuda_batch(data)).cpu()
+    with torch.no_grad():
+        want_lat = ref.transformer_forward(ref.aggregate_features(data), data["subject_id"])
+    assert (lat - want_lat).norm() / want_lat.norm() < 1e-2
+
+
+def test_missing_modality_and_text_only_config1():
+    """BASELINE config 1 shape: text only (audio / video = None -> zero-filled thirds, model.py:143-144), B=1, T=128."""
+    fdims = {"text": (2, 48), "audio": None, "video": None}
+    ref, m = _small_pair(fdims, 100, 128, 1)
+    data = tribe_ref.synthetic_batch(1, 128, fdims, 1, seed=6)
+    with torch.no_grad():
+        want = ref(data)
+    got = m(_cuda_batch(data)).cpu()
+    assert (got - want).norm() / want.norm() < 1e-2
+
+
+def test_run_step_and_metrics_vs_oracle():
+    """BrainModule.validation_step (pl_module.py:46-107,130-132): loss, streaming + grouped Pearson."""
+    from algonauts2025.main import compute_multidim_pearson
+    from algonauts2025.pl_module import BrainModule
+    from modeling_utils.losses import TorchLossConfig
+    from modeling_utils.metrics import GroupedMetricConfig, MultidimPearsonCorrCoefConfig
+
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    V, Tout, S = 50, 10, 3
+    ref, m = _small_pair(fdims, V, Tout, S)
+    metrics = {
+        "val/pearson": MultidimPearsonCorrCoefConfig(log_name="pearson", kwargs={"num_outputs": V}).build(),
+        "val/subj_pearson": GroupedMetricConfig(log_name="subj_pearson", metric_name="MultidimPearsonCorrCoef",
+                                                kwargs={"num_outputs": V}).build(),
+    }
+    bm = BrainModule(m, TorchLossConfig(name="MSELoss").build(), None, metrics)
+    batches, ref_preds, trues = [], [], []
+    for i in range(2):
+        data = tribe_ref.synthetic_batch(4, 31, fdims, S, seed=20 + i)
+        with torch.no_grad():
+            yr = ref(data)
+        data["fmri"] = 0.3 * yr + torch.randn(yr.shape, generator=torch.Generator().manual_seed(30 + i))
+        batches.append(data)
+        ref_preds.append(yr)
+        trues.append(data["fmri"])
+    for i, data in enumerate(batches):
+        y_pred, y_true = bm.validation_step(_cuda_batch(data), i)
+        assert not y_pred.is_cuda and y_pred.shape == (4, V, Tout)  # returned on CPU (pl_module.py:107)
+        want_loss, *_ = tribe_ref.run_step(y_pred, y_true, data["subject_id"])
+        assert abs(float(bm.logged["val/loss"]) - float(want_loss)) < 1e-5 * max(1.0, float(want_loss))
+    bm.on_validation_epoch_end()
+    p_ref = torch.cat([tribe_ref.flatten_bt(p) for p in ref_preds])
+    t_all = torch.cat([tribe_ref.flatten_bt(t) for t in trues])
+    r_ref = tribe_ref.scipy_pearson_columns(p_ref.numpy(), t_all.numpy())
+    r_gpu = metrics["val/pearson"].per_output()[0].cpu().numpy()
+    assert np.abs(r_gpu - r_ref).max() < 5e-3  # tiny N=80 rows here; the 3-dp criterion is tested at full size below
+    assert set(k for k in bm.logged if k.startswith("val/subj_pearson/")) == {f"val/subj_pearson/{s}" for s in range(S)}
+
+    class _Loader(list):
+        pass
+
+    r_cmp = compute_multidim_pearson(bm, _Loader([_cuda_batch(d) for d in batches]))
+    np.testing.assert_allclose(r_cmp, r_gpu, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        bm.training_step(_cuda_batch(batches[0]), 0)
+
+
+def test_full_size_pearson_parity():
+    """BASELINE.md synthetic config: T=1024, L*D=4096 per modality, V=1000, 4 subjects (B=4); fp32 CPU oracle vs
+    bf16 MFMA path; per-voxel r over the '(b t) d' flatten (main.py:459-477) must agree to 3 dp."""
+    from algonauts2025.model import FmriEncoderConfig
+
+    fdims = {"text": (2, 2048), "audio": (2, 2048), "video": (2, 2048)}
+    B, T, V, S = 4, 1024, 1000, 4
+    torch.manual_seed(0)
+    ref = tribe_ref.FmriEncoderRef(fdims, V, T, S).eval()
+    with torch.no_grad():
+        tribe_ref.fill_params_(ref, seed=0)
+    data = tribe_ref.synthetic_batch(B, T, fdims, S, seed=0)
+    with torch.no_grad():
+        y_ref = ref(data)  # [4, 1000, 1024]
+    m = FmriEncoderConfig(n_subjects=S).build(fdims, V, T).eval()
+    m.load_state_dict(ref.state_dict())
+    del ref
+    m = m.cuda()
+    y_gpu = m(_cuda_batch(data)).cpu()
+    rel = (y_gpu - y_ref).norm() / y_ref.norm()
+    fmri = 0.3 * y_ref + torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(1))
+    t_flat = tribe_ref.flatten_bt(fmri)
+    r_ref = tribe_ref.pearson_from_stats(tribe_ref.pearson_stats(tribe_ref.flatten_bt(y_ref), t_flat), B * T).numpy()
+    r_gpu = tribe_ref.pearson_from_stats(tribe_ref.pearson_stats(tribe_ref.flatten_bt(y_gpu), t_flat), B * T).numpy()
+    spot = tribe_ref.scipy_pearson_columns(tribe_ref.flatten_bt(y_ref)[:, :8].numpy(), t_flat[:, :8].numpy())
+    np.testing.assert_allclose(r_ref[:8], spot, atol=2e-6)  # the sufficient-statistics form IS scipy's r
+    dmax = np.abs(r_gpu - r_ref).max()
+    print(f"full-size parity: rel L2 err {rel:.3e}, max |dr| {dmax:.3e}, mean r {r_ref.mean():.4f}")
+    assert rel < 2e-2
+    assert dmax < PEARSON_TOL, f"per-voxel Pearson differs by {dmax:.2e} (> {PEARSON_TOL})"
