@@ -177,7 +177,7 @@ class FmriEncoder(nn.Module):
         data = self._batch_dict(batch)
         y, B, T = self._latents(data, torch.bfloat16)  # [B*T, hidden] bf16, final-normed
         out = self.predictor.forward_tokens(y.view(B, T, -1), data["subject_id"])  # [B, V, T] f32
-        if pool_outputs:
+        if pool_outputs and T != self.n_output_timesteps:  # AdaptiveAvgPool1d(T)(x[..., T]) is the identity
             out = ops.adaptive_avg_pool(out, self.n_output_timesteps)
         return out
 

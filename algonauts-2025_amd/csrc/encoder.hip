@@ -65,6 +65,7 @@ extern "C" int tribe_projector_fwd(const uint16_t* feat_packed, int64_t BT, int6
   if (accumulate) { d.res = x + col0; d.ldres = hidden; }
   if (pos_embed) { d.rowadd = pos_embed + col0; d.ld_rowadd = hidden; d.rowadd_period = T; }
   if (subj_embed) { d.gadd = subj_embed + col0; d.gadd_index = subject_id; d.gadd_div = T; d.ld_gadd = hidden; }
+  d.role = TRIBE_ROLE_PROJECTOR;
   return tribe_gemm_bf16(&d, stream);
 }
 
@@ -99,6 +100,7 @@ extern "C" int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, in
     d.B = q + inner; d.ldb = 3 * inner; d.sB1 = T * 3 * inner; d.sB0 = dim_head;
     d.C = S; d.ldc = Tp; d.sC1 = (int64_t)heads * T * Tp; d.sC0 = T * Tp; d.c_dtype = TRIBE_F32;
     d.alpha = scale;
+    d.role = TRIBE_ROLE_ATTN_SCORES;
     rc = tribe_gemm_bf16(&d, stream);
     if (rc) return rc;
     // softmax in f32 (x_transformers Attend: softmax(dtype=float32)), P rounded to bf16 for the second MFMA product
@@ -110,6 +112,7 @@ extern "C" int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, in
     d.A = P; d.lda = Tp; d.sA1 = (int64_t)heads * T * Tp; d.sA0 = T * Tp;
     d.B = Vt; d.ldb = Tp; d.sB1 = (int64_t)heads * dim_head * Tp; d.sB0 = (int64_t)dim_head * Tp;
     d.C = out + b0 * T * inner; d.ldc = inner; d.sC1 = T * inner; d.sC0 = dim_head; d.c_dtype = TRIBE_BF16;
+    d.role = TRIBE_ROLE_ATTN_PV;
     rc = tribe_gemm_bf16(&d, stream);
     if (rc) return rc;
   }
@@ -179,6 +182,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.M = M; g.N = 3 * inner; g.K = dim;
     g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
     g.C = qkv; g.ldc = 3 * inner; g.c_dtype = TRIBE_BF16;
+    g.role = TRIBE_ROLE_QKV;
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     rc = tribe_rotary_fwd(qkv, M, d->T, d->heads, d->dim_head, d->rot_dim, d->cos_tab, d->sin_tab, d->rotary_interleaved, stream);
@@ -190,6 +194,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.A = ao; g.lda = inner; g.B = L.w_out; g.ldb = inner;
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32;
     g.res = x; g.ldres = dim; g.res_scale = L.attn_res_scale;
+    g.role = TRIBE_ROLE_OUT_PROJ;
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     // ---- feed-forward block: x = W2 gelu(W1 norm(x) + b1) + b2 + x * residual_scale ----
@@ -200,6 +205,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.A = xn; g.lda = dim; g.B = L.w_ff1; g.ldb = dim;
     g.C = hbuf; g.ldc = d->ff_inner; g.c_dtype = TRIBE_BF16;
     g.bias = L.b_ff1; g.bias_mode = TRIBE_BIAS_COL; g.act = TRIBE_ACT_GELU;
+    g.role = TRIBE_ROLE_FF1;
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     g = gemm_zero();
@@ -208,6 +214,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32;
     g.bias = L.b_ff2; g.bias_mode = TRIBE_BIAS_COL;
     g.res = x; g.ldres = dim; g.res_scale = L.ff_res_scale;
+    g.role = TRIBE_ROLE_FF2;
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
   }
@@ -227,5 +234,6 @@ extern "C" int tribe_voxel_head_fwd(const uint16_t* x, int64_t B, int64_t T, int
   d.B = x; d.ldb = C_pad; d.sB1 = T * C_pad;
   d.C = y; d.ldc = T; d.sC1 = V * T; d.c_dtype = TRIBE_F32;
   if (bias) { d.bias = bias; d.bias_mode = TRIBE_BIAS_ROW; d.gather_bias = 1; d.sBias1 = V; }
+  d.role = TRIBE_ROLE_VOXEL_HEAD;
   return tribe_gemm_bf16(&d, stream);
 }

@@ -30,7 +30,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <int OUT_BF16>
+// ROLE only gives each call site of the path its own kernel symbol, so that rocprofv3 --stats and the
+// in-library HIP-event profile (tribe_prof_*) report per-operator durations; the code is identical.
+template <int OUT_BF16, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -149,6 +151,70 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------
+// Optional in-library profile: HIP events recorded on the launch stream around every GEMM launch
+// while enabled (bench.py brackets its timed region with tribe_prof_begin / tribe_prof_end).
+// ---------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t start, stop; int role; double flops; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+bool g_prof_on = false;
+
+int prof_before(int role, double flops, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  if (!g_prof_on || g_prof_used >= g_prof.size()) return -1;
+  const int slot = (int)g_prof_used++;
+  g_prof[slot].role = role;
+  g_prof[slot].flops = flops;
+  (void)hipEventRecord(g_prof[slot].start, s);
+  return slot;
+}
+void prof_after(int slot, hipStream_t s) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  (void)hipEventRecord(g_prof[slot].stop, s);
+}
+}  // namespace
+
+extern "C" int tribe_prof_begin(int32_t max_records) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  TRIBE_REQUIRE(max_records > 0, "tribe_prof_begin: max_records must be positive");
+  while ((int)g_prof.size() < max_records) {
+    ProfRec r{};
+    hipError_t e = hipEventCreate(&r.start);
+    if (e == hipSuccess) e = hipEventCreate(&r.stop);
+    if (e != hipSuccess) { tribe_set_error("tribe_prof_begin: hipEventCreate failed: %s", hipGetErrorString(e)); return (int)e; }
+    g_prof.push_back(r);
+  }
+  g_prof_used = 0;
+  g_prof_on = true;
+  return 0;
+}
+
+extern "C" int tribe_prof_end(int32_t n_roles, double* total_ms_host, int64_t* count_host, double* flops_host) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  TRIBE_REQUIRE(total_ms_host && count_host && flops_host && n_roles >= TRIBE_ROLE_COUNT, "tribe_prof_end: need %d role slots",
+                TRIBE_ROLE_COUNT);
+  g_prof_on = false;
+  for (int i = 0; i < n_roles; ++i) { total_ms_host[i] = 0.0; count_host[i] = 0; flops_host[i] = 0.0; }
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    hipError_t e = hipEventSynchronize(g_prof[i].stop);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof[i].start, g_prof[i].stop);
+    if (e != hipSuccess) { tribe_set_error("tribe_prof_end: event query failed: %s", hipGetErrorString(e)); return (int)e; }
+    total_ms_host[g_prof[i].role] += (double)ms;
+    count_host[g_prof[i].role] += 1;
+    flops_host[g_prof[i].role] += g_prof[i].flops;
+  }
+  g_prof_used = 0;
+  return 0;
+}
+
 extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(d != nullptr, "tribe_gemm_bf16: null descriptor");
   TRIBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "tribe_gemm_bf16: M, N, K must be positive (got %lld %lld %lld)",
@@ -170,18 +236,35 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   const int64_t nz = d->batch1 * d->batch0;
   TRIBE_REQUIRE(tiles_m * tiles_n < (1ll << 31) && nz < 65536, "tribe_gemm_bf16: grid too large");
 
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_128x128x64<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_128x128x64<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    attr_set = true;
-  }
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nz, 1), block(256, 1, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (d->c_dtype == TRIBE_BF16)
-    hipLaunchKernelGGL(gemm_nt_128x128x64<1>, grid, block, SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
-  else
-    hipLaunchKernelGGL(gemm_nt_128x128x64<0>, grid, block, SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
+  const int role = (d->role >= 0 && d->role < TRIBE_ROLE_COUNT) ? d->role : TRIBE_ROLE_GENERIC;
+  const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K * (double)nz;
+  const int slot = prof_before(role, flops, s);
+#define TRIBE_GEMM_LAUNCH(BF, ROLE)                                                                                  \
+  do {                                                                                                               \
+    static bool attr_done = false;                                                                                   \
+    if (!attr_done) {                                                                                                \
+      (void)hipFuncSetAttribute((const void*)gemm_nt_128x128x64<BF, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                SMEM_BYTES);                                                                         \
+      attr_done = true;                                                                                              \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_nt_128x128x64<BF, ROLE>), grid, block, SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);  \
+  } while (0)
+  const bool bf = d->c_dtype == TRIBE_BF16;
+  switch (role) {
+    case TRIBE_ROLE_PROJECTOR: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_PROJECTOR); break;
+    case TRIBE_ROLE_QKV: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_QKV); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
+    case TRIBE_ROLE_ATTN_SCORES: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_ATTN_SCORES); break;
+    case TRIBE_ROLE_ATTN_PV: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_ATTN_PV); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
+    case TRIBE_ROLE_OUT_PROJ: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_OUT_PROJ); break;
+    case TRIBE_ROLE_FF1: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_FF1); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
+    case TRIBE_ROLE_FF2: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_FF2); break;
+    case TRIBE_ROLE_VOXEL_HEAD: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_VOXEL_HEAD); break;
+    default: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
+  }
+#undef TRIBE_GEMM_LAUNCH
+  prof_after(slot, s);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

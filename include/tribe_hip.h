@@ -35,6 +35,12 @@ extern "C" {
 enum tribe_dtype { TRIBE_F32 = 0, TRIBE_BF16 = 1, TRIBE_F64 = 2 };
 enum tribe_act { TRIBE_ACT_NONE = 0, TRIBE_ACT_GELU = 1 };
 enum tribe_bias_mode { TRIBE_BIAS_NONE = 0, TRIBE_BIAS_COL = 1, TRIBE_BIAS_ROW = 2 };
+/* which operator of the path a GEMM launch serves: selects the kernel SYMBOL (per-operator rows in
+ * rocprofv3 --stats and in the tribe_prof_* event profile); arithmetic is identical for all roles */
+enum tribe_gemm_role {
+  TRIBE_ROLE_GENERIC = 0, TRIBE_ROLE_PROJECTOR = 1, TRIBE_ROLE_QKV = 2, TRIBE_ROLE_ATTN_SCORES = 3, TRIBE_ROLE_ATTN_PV = 4,
+  TRIBE_ROLE_OUT_PROJ = 5, TRIBE_ROLE_FF1 = 6, TRIBE_ROLE_FF2 = 7, TRIBE_ROLE_VOXEL_HEAD = 8, TRIBE_ROLE_COUNT = 9
+};
 
 int tribe_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -65,9 +71,16 @@ typedef struct tribe_gemm_desc {
   const float* res_scale;  /* f32 [N] or NULL (= 1) */
   const float* rowadd; int64_t ld_rowadd, rowadd_period; /* + rowadd[(m % period)][n] */
   const float* gadd; const int64_t* gadd_index; int64_t gadd_div, ld_gadd; /* + gadd[gadd_index[m / div]][n] */
+  int32_t role;            /* enum tribe_gemm_role */
 } tribe_gemm_desc;
 
 int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);
+
+/* Measurement hook (bench.py): while enabled, every GEMM launch is bracketed by HIP events on ITS
+ * stream.  tribe_prof_end synchronises them and returns, per role, the summed kernel time (ms), the
+ * launch count and the summed algorithmic FLOPs (2*M*N*K*batches).  Host arrays of >= TRIBE_ROLE_COUNT. */
+int tribe_prof_begin(int32_t max_records);
+int tribe_prof_end(int32_t n_roles, double* total_ms_host, int64_t* count_host, double* flops_host);
 
 /* ------------------------------------------------------------------------- *
  * Packing (one-time per parameter version; fp32 master weights stay in torch)
