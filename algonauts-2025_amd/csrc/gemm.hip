@@ -1,39 +1,194 @@
 // bf16 MFMA GEMM for gfx950:  C = epi(alpha * A . B^T),  A [M,K], B [N,K], K contiguous.
 //
-// Tile 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 4x4
-// v_mfma_f32_16x16x32_bf16 accumulators).  Operands are staged HBM -> LDS with
-// global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into two LDS
-// buffers; the LDS image is lane-linear (a glds requirement), so the bank-conflict
-// swizzle chunk ^= (row & 7) is applied to the per-lane SOURCE address and undone
-// on the ds_read_b128 fragment read (cdna_hip_programming.md rule 21 / T2).
-// Roofline: MFMA (dense bf16) -- see DESIGN.md "Kernels".
-#include "common.h"
+// Two tile configurations share one operator epilogue (gemm_common.h):
+//  * 256x256x64, 512 threads (8 waves as 2x4, 128x64 per wave, 8x4 v_mfma_f32_16x16x32_bf16
+//    accumulators), 128 KiB LDS = 2 K-tile buffers.  Operands go HBM/L2 -> LDS with
+//    global_load_lds_dwordx4 (no VGPR round trip) in "half-tiles" of 128 rows, one half-tile per
+//    phase, four phases per K-tile (one C quadrant = 16 MFMAs per wave each).  Loads stay in flight
+//    across the raw s_barriers behind a COUNTED s_waitcnt vmcnt(6): three half-tiles (of K-tile t+2)
+//    are always outstanding while K-tile t computes (the 8-phase schedule of cdna_hip_programming.md
+//    section 5, re-derived: a half-tile is the set of rows read in ONE phase, so it can be restaged
+//    one phase after that phase).
+//  * 128x128x64, 256 threads (4 waves, 64x64 per wave), double buffered, one vmcnt(0)+barrier per
+//    K-tile: used when M or N is too small to fill 256-wide tiles.
+// The LDS image is lane-linear (a glds requirement), so the bank-conflict swizzle
+// chunk ^= (row & 7) is applied to the per-lane SOURCE address and undone on the ds_read_b128
+// fragment read (guide rule 21 / T2).  Roofline: MFMA (dense bf16) -- see DESIGN.md "Kernels".
+#include "gemm_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
+
+// =============================================================================================
+// 256 x 256 x 64, counted-vmcnt pipeline
+// =============================================================================================
+namespace big {
+constexpr int BM = 256, BN = 256;
+constexpr int A_BYTES = BM * BK * 2;          // 32 KiB
+constexpr int BUF_BYTES = 2 * A_BYTES;        // A + B of one K-tile: 64 KiB
+constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // 128 KiB
+}  // namespace big
+
+#define TRIBE_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int OUT_BF16, int ROLE>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
+  using namespace big;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int64_t z = blockIdx.y;
+  const int64_t b1 = z / g.batch0, b0 = z - b1 * g.batch0;
+  const int64_t b1g = g.gather1 ? g.gather1[b1] : b1;
+  const unsigned short* A = (const unsigned short*)g.A + (g.gather_a ? b1g : b1) * g.sA1 + b0 * g.sA0;
+  const unsigned short* B = (const unsigned short*)g.B + b1 * g.sB1 + b0 * g.sB0;
+
+  // ---- staging: half-tile = the 128 tile rows read in one phase; each wave moves 2 slabs of 8 rows ----
+  //   A half h: rows {wr'*128 + h*64 + 0..63, wr' = 0,1};   slab j of this wave: row0 = j*128 + h*64 + wave*8
+  //   B half h: rows {wc'*64 + h*32 + 0..31, wc' = 0..3};   slab j of this wave: row0 = (2j + (wave>>2))*64 + h*32 + (wave&3)*8
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ srow;  // swizzle on the SOURCE chunk (row & 7 == srow for every slab)
+  const unsigned short* a_src[2][2];
+  const unsigned short* b_src[2][2];
+  int a_lds[2][2], b_lds[2][2];  // wave-uniform LDS byte offsets of the slabs inside a K-tile buffer
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ra = j * 128 + h * 64 + wave * 8;
+      const int rb = (2 * j + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8;
+      int64_t gr = m0 + ra + srow; gr = gr < g.M ? gr : g.M - 1;  // clamp: edge rows re-read a valid row, stores are masked
+      int64_t gc = n0 + rb + srow; gc = gc < g.N ? gc : g.N - 1;
+      a_src[h][j] = A + gr * g.lda + schunk * 8;
+      b_src[h][j] = B + gc * g.ldb + schunk * 8;
+      a_lds[h][j] = ra * 128;
+      b_lds[h][j] = A_BYTES + rb * 128;
+    }
+
+  // which: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1
+  auto stage = [&](int which, int buf, int kt) {
+    char* base = smem + buf * BUF_BYTES;
+    const int koff = kt * BK;
+    if (which == 0 || which == 3) {
+      const int h = which == 3;
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][0] + koff), (lptr_t)(base + a_lds[h][0]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][1] + koff), (lptr_t)(base + a_lds[h][1]), 16, 0, 0);
+    } else {
+      const int h = which == 2;
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][0] + koff), (lptr_t)(base + b_lds[h][0]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][1] + koff), (lptr_t)(base + b_lds[h][1]), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int coff0 = ((fq ^ (frow & 7)) << 4), coff1 = (((4 + fq) ^ (frow & 7)) << 4);
+  const int a_rd = (wr * 128 + frow) * 128;            // + mh*8192 + i*2048 + coff
+  const int b_rd = A_BYTES + (wc * 64 + frow) * 128;   // + nh*4096 + j*2048 + coff
+
+  bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+
+#define TRIBE_LDS_A(base, MH)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+    fa[i][0] = *(const bf16x8_t*)((base) + a_rd + (MH) * 8192 + i * 2048 + coff0);             \
+    fa[i][1] = *(const bf16x8_t*)((base) + a_rd + (MH) * 8192 + i * 2048 + coff1);             \
+  }
+#define TRIBE_LDS_B(base, NH, FB)                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+    FB[j][0] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff0);             \
+    FB[j][1] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff1);             \
+  }
+#define TRIBE_MMA(MH, NH, FB)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+    acc[(MH) * 4 + i][(NH) * 2 + j] =                                                          \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], FB[j][0], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+    acc[(MH) * 4 + i][(NH) * 2 + j] =                                                          \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], FB[j][1], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+  }
+#define TRIBE_PHASE_SYNC_MMA(MH, NH, FB)        \
+  __builtin_amdgcn_s_barrier();                 \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0);            \
+  __builtin_amdgcn_s_setprio(1);                \
+  TRIBE_MMA(MH, NH, FB)                         \
+  __builtin_amdgcn_s_setprio(0);                \
+  __builtin_amdgcn_s_barrier();
+
+  const int nk = (int)(g.K / BK);
+
+  // ---- prologue: K-tile 0 completely, K-tile 1 minus its last half-tile ----
+  stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
+  if (nk > 1) {
+    stage(0, 1, 1); stage(1, 1, 1); stage(2, 1, 1);
+    TRIBE_WAIT_VMCNT(6);
+  } else {
+    TRIBE_WAIT_VMCNT(0);
+  }
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const char* base = smem + cur * BUF_BYTES;
+    // phase 1: quadrant (m-half 0, n-half 0); restage: last half-tile (A half 1) of K-tile t+1
+    TRIBE_LDS_B(base, 0, fb0)
+    TRIBE_LDS_A(base, 0)
+    if (t + 1 < nk) stage(3, cur ^ 1, t + 1);
+    TRIBE_PHASE_SYNC_MMA(0, 0, fb0)
+    // phase 2: (0, 1); A half 0 of THIS buffer was last read in phase 1 -> restage it for K-tile t+2
+    TRIBE_LDS_B(base, 1, fb1)
+    if (t + 2 < nk) stage(0, cur, t + 2);
+    TRIBE_PHASE_SYNC_MMA(0, 1, fb1)
+    // phase 3: (1, 1); B half 0 was last read in phase 1
+    TRIBE_LDS_A(base, 1)
+    if (t + 2 < nk) stage(1, cur, t + 2);
+    TRIBE_PHASE_SYNC_MMA(1, 1, fb1)
+    // phase 4: (1, 0) from registers only; B half 1 was last read in phase 2.  Then retire K-tile t+1:
+    // everything issued before the three half-tiles of K-tile t+2 must have landed.
+    if (t + 2 < nk) { stage(2, cur, t + 2); TRIBE_WAIT_VMCNT(6); } else { TRIBE_WAIT_VMCNT(0); }
+    TRIBE_PHASE_SYNC_MMA(1, 0, fb0)
+  }
+#undef TRIBE_LDS_A
+#undef TRIBE_LDS_B
+#undef TRIBE_MMA
+#undef TRIBE_PHASE_SYNC_MMA
+
+  const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      epilogue_tile16<OUT_BF16>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * 64 + j * 16, lane);
+}
+
+// =============================================================================================
+// 128 x 128 x 64, double buffered
+// =============================================================================================
+namespace small {
+constexpr int BM = 128, BN = 128;
 constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;     // A + B
 constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // double buffered: 64 KiB
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  // bijective "each XCD gets a contiguous chunk of tiles" remap (T1); speed only
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
-}
+}  // namespace small
 
 // ROLE only gives each call site of the path its own kernel symbol, so that rocprofv3 --stats and the
 // in-library HIP-event profile (tribe_prof_*) report per-operator durations; the code is identical.
 template <int OUT_BF16, int ROLE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
+  using namespace small;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -112,44 +267,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
     __syncthreads();
   }
 
-  // ---- epilogue: D[row = 4*fq + reg][col = frow] per 16x16 tile ----
-  const int64_t bb = g.gather_bias ? b1g : b1;
-  const float* bias = g.bias ? g.bias + bb * g.sBias1 : nullptr;
-  const float* res = g.res ? g.res + b1 * g.sRes1 + b0 * g.sRes0 : nullptr;
-  char* Cb = (char*)g.C;
-  const int64_t c_off = b1 * g.sC1 + b0 * g.sC0;
+  const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int64_t m = m0 + wr * 64 + i * 16 + fq * 4 + reg;
-      if (m >= g.M) continue;
-      const float* rowadd = g.rowadd ? g.rowadd + (m % g.rowadd_period) * g.ld_rowadd : nullptr;
-      const float* gadd = g.gadd ? g.gadd + g.gadd_index[m / g.gadd_div] * g.ld_gadd : nullptr;
-      const float brow = (g.bias_mode == TRIBE_BIAS_ROW) ? bias[m] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t n = n0 + wc * 64 + j * 16 + frow;
-        if (n >= g.N) continue;
-        float v = acc[i][j][reg] * g.alpha;
-        if (g.bias_mode == TRIBE_BIAS_COL) v += bias[n];
-        else if (g.bias_mode == TRIBE_BIAS_ROW) v += brow;
-        if (g.act == TRIBE_ACT_GELU) v = gelu_erf(v);
-        if (res) {
-          const float r = res[m * g.ldres + n];
-          v += g.res_scale ? r * g.res_scale[n] : r;
-        }
-        if (rowadd) v += rowadd[n];
-        if (gadd) v += gadd[n];
-        const int64_t idx = c_off + m * g.ldc + n;
-        if (OUT_BF16) ((unsigned short*)Cb)[idx] = f32_to_bf16(v);
-        else ((float*)Cb)[idx] = v;
-      }
-    }
-  }
+    for (int j = 0; j < 4; ++j)
+      epilogue_tile16<OUT_BF16>(g, ctx, acc[i][j], m0 + wr * 64 + i * 16, n0 + wc * 64 + j * 16, lane);
 }
 
 }  // namespace
+
 
 
 // ---------------------------------------------------------------------------------------------
@@ -232,24 +359,33 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(!d->rowadd || d->rowadd_period > 0, "tribe_gemm_bf16: rowadd needs a positive period");
   TRIBE_REQUIRE(!d->gadd || (d->gadd_index && d->gadd_div > 0), "tribe_gemm_bf16: gadd needs index and divisor");
   TRIBE_REQUIRE(!(d->gather_a || d->gather_bias) || d->gather1, "tribe_gemm_bf16: gather flags set without gather1");
-  const int64_t tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN;
   const int64_t nz = d->batch1 * d->batch0;
+  // tile selection: 256^2 tiles when both extents fill them and the grid still covers the chip, else 128^2
+  int use_big = (d->M >= 256 && d->N >= 256 && ((d->M + 255) / 256) * ((d->N + 255) / 256) * nz >= 96);
+  if (d->tile_hint == 1) use_big = 0;
+  if (d->tile_hint == 2) use_big = 1;
+  const int64_t bm = use_big ? big::BM : small::BM, bn = use_big ? big::BN : small::BN;
+  const int64_t tiles_m = (d->M + bm - 1) / bm, tiles_n = (d->N + bn - 1) / bn;
   TRIBE_REQUIRE(tiles_m * tiles_n < (1ll << 31) && nz < 65536, "tribe_gemm_bf16: grid too large");
 
-  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nz, 1), block(256, 1, 1);
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nz, 1);
   hipStream_t s = (hipStream_t)stream;
   const int role = (d->role >= 0 && d->role < TRIBE_ROLE_COUNT) ? d->role : TRIBE_ROLE_GENERIC;
   const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K * (double)nz;
   const int slot = prof_before(role, flops, s);
-#define TRIBE_GEMM_LAUNCH(BF, ROLE)                                                                                  \
-  do {                                                                                                               \
-    static bool attr_done = false;                                                                                   \
-    if (!attr_done) {                                                                                                \
-      (void)hipFuncSetAttribute((const void*)gemm_nt_128x128x64<BF, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                SMEM_BYTES);                                                                         \
-      attr_done = true;                                                                                              \
-    }                                                                                                                \
-    hipLaunchKernelGGL((gemm_nt_128x128x64<BF, ROLE>), grid, block, SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);  \
+#define TRIBE_GEMM_LAUNCH_K(KERNEL, THREADS, SMEM, BF, ROLE)                                                 \
+  do {                                                                                                       \
+    static bool attr_done = false;                                                                           \
+    if (!attr_done) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)KERNEL<BF, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
+      attr_done = true;                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL((KERNEL<BF, ROLE>), grid, dim3(THREADS, 1, 1), SMEM, s, *d, (int)tiles_m, (int)tiles_n); \
+  } while (0)
+#define TRIBE_GEMM_LAUNCH(BF, ROLE)                                                                          \
+  do {                                                                                                       \
+    if (use_big) TRIBE_GEMM_LAUNCH_K(gemm_nt_256x256x64, 512, big::SMEM_BYTES, BF, ROLE);                    \
+    else TRIBE_GEMM_LAUNCH_K(gemm_nt_128x128x64, 256, small::SMEM_BYTES, BF, ROLE);                          \
   } while (0)
   const bool bf = d->c_dtype == TRIBE_BF16;
   switch (role) {
@@ -264,6 +400,7 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
     default: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
   }
 #undef TRIBE_GEMM_LAUNCH
+#undef TRIBE_GEMM_LAUNCH_K
   prof_after(slot, s);
   TRIBE_LAUNCH_CHECK();
   return 0;

@@ -1,0 +1,133 @@
+// Pieces shared by the two MFMA GEMM tile configurations (gemm.hip): the operator epilogue and the
+// XCD-aware tile remap.
+#pragma once
+#include "common.h"
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// bijective "each XCD gets a contiguous chunk of tiles" remap (guide T1); changes speed only
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// quad-lane exchanges as DPP moves (no LDS traffic): lane i <- lane i^1 / i^2 within each group of 4
+__device__ __forceinline__ float quad_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+struct EpiCtx {
+  const float* bias;   // already offset by the (gathered) batch
+  const float* res;    // already offset by the batch
+  char* C;             // base of C (bytes), NOT offset
+  int64_t c_off;       // element offset of this batch
+  bool vec;            // every operand the epilogue touches allows 4-wide vector access
+};
+
+__device__ __forceinline__ EpiCtx make_epi_ctx(const tribe_gemm_desc& g, int64_t b1, int64_t b0, int64_t b1g) {
+  EpiCtx c;
+  const int64_t bb = g.gather_bias ? b1g : b1;
+  c.bias = g.bias ? g.bias + bb * g.sBias1 : nullptr;
+  c.res = g.res ? g.res + b1 * g.sRes1 + b0 * g.sRes0 : nullptr;
+  c.C = (char*)g.C;
+  c.c_off = b1 * g.sC1 + b0 * g.sC0;
+  const int esz = (g.c_dtype == TRIBE_BF16) ? 2 : 4;
+  bool v = ((g.ldc & 3) == 0) && ((c.c_off & 3) == 0) && ((((uintptr_t)g.C) & (uintptr_t)(4 * esz - 1)) == 0);
+  if (g.bias_mode == TRIBE_BIAS_COL) v = v && ((((uintptr_t)c.bias) & 15) == 0);
+  if (c.res) v = v && ((g.ldres & 3) == 0) && ((((uintptr_t)c.res) & 15) == 0);
+  if (g.res_scale) v = v && ((((uintptr_t)g.res_scale) & 15) == 0);
+  if (g.rowadd) v = v && ((g.ld_rowadd & 3) == 0) && ((((uintptr_t)g.rowadd) & 15) == 0);
+  if (g.gadd) v = v && ((g.ld_gadd & 3) == 0) && ((((uintptr_t)g.gadd) & 15) == 0);
+  c.vec = v;
+  return c;
+}
+
+// One 16x16 accumulator tile (v_mfma_f32_16x16x32 C/D map: acc[r] = D[4*(lane>>4) + r][lane & 15]) ->
+// epi(...) -> C.  A 4x4 transpose inside each quad of lanes turns "4 rows x 1 column" per lane into
+// "1 row x 4 consecutive columns", so every lane issues ONE 16-byte (f32) / 8-byte (bf16) store and
+// reads its residual / bias operands as float4.
+template <int OUT_BF16>
+__device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t acc, int64_t mt0,
+                                                int64_t nt0, int lane) {
+  const int a = lane & 3;
+  float v0 = acc[0] * g.alpha, v1 = acc[1] * g.alpha, v2 = acc[2] * g.alpha, v3 = acc[3] * g.alpha;
+  {
+    const bool b0 = a & 1, b1 = a & 2;
+    const float t0 = quad_xor1(b0 ? v0 : v1), t1 = quad_xor1(b0 ? v2 : v3);
+    if (b0) { v0 = t0; v2 = t1; } else { v1 = t0; v3 = t1; }
+    const float u0 = quad_xor2(b1 ? v0 : v2), u1 = quad_xor2(b1 ? v1 : v3);
+    if (b1) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
+  }
+  const int64_t m = mt0 + ((lane >> 4) << 2) + a;
+  const int64_t n = nt0 + (((lane & 15) >> 2) << 2);
+  if (m >= g.M || n >= g.N) return;
+  float v[4] = {v0, v1, v2, v3};
+  if (g.bias_mode == TRIBE_BIAS_ROW) {
+    const float b = c.bias[m];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += b;
+  }
+  const float* rowadd = g.rowadd ? g.rowadd + (m % g.rowadd_period) * g.ld_rowadd : nullptr;
+  const float* gadd = g.gadd ? g.gadd + g.gadd_index[m / g.gadd_div] * g.ld_gadd : nullptr;
+  const int64_t idx = c.c_off + m * g.ldc + n;
+  if (c.vec && n + 4 <= g.N) {
+    if (g.bias_mode == TRIBE_BIAS_COL) {
+      const float4 b = *(const float4*)(c.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (g.act == TRIBE_ACT_GELU) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
+    }
+    if (c.res) {
+      const float4 r = *(const float4*)(c.res + m * g.ldres + n);
+      if (g.res_scale) {
+        const float4 s = *(const float4*)(g.res_scale + n);
+        v[0] += r.x * s.x; v[1] += r.y * s.y; v[2] += r.z * s.z; v[3] += r.w * s.w;
+      } else {
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+    }
+    if (rowadd) {
+      const float4 r = *(const float4*)(rowadd + n);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (gadd) {
+      const float4 r = *(const float4*)(gadd + n);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (OUT_BF16) {
+      u16x4_t o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
+      *(u16x4_t*)((unsigned short*)c.C + idx) = o;
+    } else {
+      *(float4*)((float*)c.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (n + k >= g.N) break;
+    float x = v[k];
+    if (g.bias_mode == TRIBE_BIAS_COL) x += c.bias[n + k];
+    if (g.act == TRIBE_ACT_GELU) x = gelu_erf(x);
+    if (c.res) {
+      const float r = c.res[m * g.ldres + n + k];
+      x += g.res_scale ? r * g.res_scale[n + k] : r;
+    }
+    if (rowadd) x += rowadd[n + k];
+    if (gadd) x += gadd[n + k];
+    if (OUT_BF16) ((unsigned short*)c.C)[idx + k] = f32_to_bf16(x);
+    else ((float*)c.C)[idx + k] = x;
+  }
+}

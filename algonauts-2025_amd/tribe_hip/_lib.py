@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
         ("res_scale", vp),
         ("rowadd", vp), ("ld_rowadd", i64), ("rowadd_period", i64),
         ("gadd", vp), ("gadd_index", vp), ("gadd_div", i64), ("ld_gadd", i64),
-        ("role", i32),
+        ("role", i32), ("tile_hint", i32),
     ]
 
 

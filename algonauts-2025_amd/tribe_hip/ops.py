@@ -64,7 +64,7 @@ def gemm_nt(
     res: torch.Tensor | None = None, res_scale: torch.Tensor | None = None, alpha: float = 1.0,
     out_dtype: torch.dtype = torch.float32, out: torch.Tensor | None = None,
     rowadd: torch.Tensor | None = None, rowadd_period: int = 0,
-    gadd: torch.Tensor | None = None, gadd_index: torch.Tensor | None = None, gadd_div: int = 0,
+    gadd: torch.Tensor | None = None, gadd_index: torch.Tensor | None = None, gadd_div: int = 0, tile_hint: int = 0,
 ) -> torch.Tensor:
     """out[..., m, n] = epi(alpha * sum_k a[..., m, k] * b[..., n, k]); a, b bf16 with equal leading batch dim (or 2-D)."""
     _cuda(a, torch.bfloat16, "a")
@@ -87,6 +87,7 @@ def gemm_nt(
     d.C, d.ldc, d.sC1 = out.data_ptr(), N, M * N
     d.c_dtype = _DT[out.dtype]
     d.alpha = alpha
+    d.tile_hint = tile_hint
     if bias is not None:
         _cuda(bias, torch.float32, "bias")
         d.bias, d.bias_mode = bias.data_ptr(), (_lib.BIAS_ROW if bias_row else _lib.BIAS_COL)

@@ -171,7 +171,7 @@ def main() -> None:
                                "achieved_tflops": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
         dom = max(prof, key=lambda k: prof[k]["ms"])
         gemm_ms = sum(r["ms"] for r in prof.values()) / args.steps
-        roofline = {"bound": "mfma", "kernel": f"gemm_nt_128x128x64<{dom}>", "achieved": by_kernel[dom]["achieved_tflops"],
+        roofline = {"bound": "mfma", "kernel": f"gemm_nt_256x256x64<{dom}>", "achieved": by_kernel[dom]["achieved_tflops"],
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": by_kernel[dom]["frac"], "traffic": None,
                     "avg_launch_ms": by_kernel[dom]["avg_ms"], "flops_per_launch": by_kernel[dom]["gflop_per_launch"] * 1e9,
                     "by_kernel": by_kernel,

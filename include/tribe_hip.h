@@ -72,6 +72,7 @@ typedef struct tribe_gemm_desc {
   const float* rowadd; int64_t ld_rowadd, rowadd_period; /* + rowadd[(m % period)][n] */
   const float* gadd; const int64_t* gadd_index; int64_t gadd_div, ld_gadd; /* + gadd[gadd_index[m / div]][n] */
   int32_t role;            /* enum tribe_gemm_role */
+  int32_t tile_hint;       /* 0 = automatic, 1 = force 128x128 tiles, 2 = force 256x256 tiles (tests / tuning) */
 } tribe_gemm_desc;
 
 int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);

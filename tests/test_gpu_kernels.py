@@ -39,36 +39,51 @@ def test_gemm_identity_asymmetric(ops):
     torch.testing.assert_close(out.cpu(), b.t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1000, 192), (1000, 298, 3072), (4, 5, 64), (129, 129, 64)])
-def test_gemm_shapes(ops, M, N, K):
+@pytest.mark.parametrize("tile_hint", [1, 2])  # 1 = 128x128 tiles, 2 = 256x256 tiles (counted-vmcnt pipeline)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1000, 192), (1000, 298, 3072), (4, 5, 64), (129, 129, 64),
+                                   (256, 256, 64), (512, 768, 320), (257, 511, 128), (1024, 1024, 384)])
+def test_gemm_shapes(ops, M, N, K, tile_hint):
     g = torch.Generator().manual_seed(M * 7 + N)
     a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g))
-    out = ops.gemm_nt(_dev(a).bfloat16(), _dev(b).bfloat16())
+    out = ops.gemm_nt(_dev(a).bfloat16(), _dev(b).bfloat16(), tile_hint=tile_hint)
     ref = a.double() @ b.double().t()
     torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-4 * K**0.5)
 
 
-def test_gemm_epilogues(ops):
+def test_gemm_big_tiles_race_screen(ops):
+    """The 256x256 kernel keeps LDS-DMA loads in flight across barriers behind counted waits: an ordering bug
+    shows as rare wrong tiles, so hammer one long-K problem repeatedly and demand bit-identical results."""
+    g = torch.Generator().manual_seed(99)
+    a, b = _dev(torch.randn(1024, 4096, generator=g)).bfloat16(), _dev(torch.randn(1536, 4096, generator=g)).bfloat16()
+    first = ops.gemm_nt(a, b, tile_hint=2)
+    ref = ops.gemm_nt(a, b, tile_hint=1)
+    torch.testing.assert_close(first, ref, rtol=1e-5, atol=2e-3)  # different K-summation order only
+    for _ in range(20):
+        assert torch.equal(ops.gemm_nt(a, b, tile_hint=2), first)
+
+
+@pytest.mark.parametrize("M,N,hint", [(96, 160, 0), (96, 158, 0), (384, 320, 2)])
+def test_gemm_epilogues(ops, M, N, hint):
     g = torch.Generator().manual_seed(3)
-    M, N, K, T = 96, 160, 128, 32
+    K, T = 128, 32
     a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / K**0.5)
     bias, rs = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
     res = torch.randn(M, N, generator=g)
     rowadd = torch.randn(T, N, generator=g)
-    gadd, gidx = torch.randn(5, N, generator=g), torch.tensor([4, 0, 2])
+    gadd, gidx = torch.randn(5, N, generator=g), torch.tensor([4, 0, 2] * 4)
     A, B = _dev(a).bfloat16(), _dev(b).bfloat16()
     base = a @ b.t()
     # bias + gelu, bf16 out  (one bf16 rounding: rel 2^-8 worst case)
-    out = ops.gemm_nt(A, B, bias=_dev(bias), act="gelu", out_dtype=torch.bfloat16)
+    out = ops.gemm_nt(A, B, bias=_dev(bias), act="gelu", out_dtype=torch.bfloat16, tile_hint=hint)
     torch.testing.assert_close(out.float().cpu(), torch.nn.functional.gelu(base + bias), rtol=2**-7, atol=1e-3)
     # residual * scale + bias, in place on the residual buffer
     x = _dev(res.clone())
-    ops.gemm_nt(A, B, bias=_dev(bias), res=x, res_scale=_dev(rs), out=x)
+    ops.gemm_nt(A, B, bias=_dev(bias), res=x, res_scale=_dev(rs), out=x, tile_hint=hint)
     torch.testing.assert_close(x.cpu(), base + bias + res * rs, rtol=1e-5, atol=1e-4)
     # alpha, row bias, rowadd (period T) and gathered add (div T)
     rb = torch.randn(M, generator=g)
     out = ops.gemm_nt(A, B, alpha=0.25, bias=_dev(rb), bias_row=True, rowadd=_dev(rowadd), rowadd_period=T, gadd=_dev(gadd),
-                      gadd_index=_dev(gidx), gadd_div=T)
+                      gadd_index=_dev(gidx), gadd_div=T, tile_hint=hint)
     m = torch.arange(M)
     want = 0.25 * base + rb[:, None] + rowadd[m % T] + gadd[gidx[m // T]]
     torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=1e-4)
