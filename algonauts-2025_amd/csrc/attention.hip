@@ -1,0 +1,256 @@
+// Fused bidirectional attention forward for gfx950:  out = softmax(q k^T * scale) v  per (batch, head),
+// reading q / k / v straight out of the fused qkv projection buffer [B*T, 3*heads*DH] (bf16, rotary
+// already applied) and never materialising the [T, T] score matrix (x_transformers Attend, called via
+// model.py:173; the reference runs it with attn_flash=False, i.e. materialised in HBM).
+//
+// Work split: one 512-thread workgroup = 128 query rows of one (batch, head); wave w owns 16 of them
+// (two waves per SIMD, <= 256 registers each -- with DH = 384 a 32-row wave would need 192 accumulator
+// + 96 Q registers and spills):
+//   * Q^T fragments for all DH/32 k-steps live in registers (48 VGPRs at DH = 384);
+//   * S^T = K . Q^T  with v_mfma_f32_16x16x32_bf16: A = K tile rows (keys) from LDS (ds_read_b128),
+//     B = Q^T from registers.  The accumulator puts the query on the LANE (col = lane & 15), so the
+//     online-softmax state (running max m, running sum l) is one scalar per lane;
+//   * P^T (bf16) is the pair of S^T accumulators (keys 0-15 / 16-31 of the tile) re-used directly as the
+//     B operand of the second product  O^T += V^T . P^T  (guide section 3 "An accumulator tile as the
+//     next MFMA's operand"): k-slot 8*(lane>>4)+j of the MFMA is key 4*(lane>>4)+j (j < 4) or
+//     16+4*(lane>>4)+j-4 (j >= 4), and the A operand V^T is read from the row-major V tile with
+//     ds_read_b64_tr_b16 (hardware transpose) in exactly that key order;
+//   * O^T [DH x 16 queries] stays in accumulators (96 registers at DH = 384) for the whole key loop; it is
+//     rescaled only when some row maximum grew by more than 2^8 (deferred max, guide T13).
+// K / V tiles of 32 keys are staged HBM -> LDS by global_load_lds_dwordx4 into two buffers; the 16-byte
+// chunk swizzle  chunk ^= (row & 7) << 1  (applied on the SOURCE address, undone on the reads) keeps both
+// the row reads of K and the transposed reads of V bank-conflict free.
+// Roofline: MFMA (4*T*DH flop per query row and head); every MFMA streams a 1 KiB operand from LDS, so
+// the LDS read rate (256 B/clk/CU) is the co-bound.
+#include "gemm_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <int DH>
+struct AttnCfg {
+  static constexpr int KS = DH / 32;            // k-steps of S^T = K Q^T (16x16x32)
+  static constexpr int DT = DH / 16;            // 16-row tiles of O^T
+  static constexpr int ROWB = DH * 2;           // bytes per K / V tile row
+  static constexpr int KV = 32;                 // keys per tile
+  static constexpr int TILE_BYTES = KV * ROWB;  // one K or V tile
+  static constexpr int CHUNKS = DH / 8;         // 16-byte chunks per row
+  static constexpr int WAVES = 8;
+  static constexpr int PIECES = KV * CHUNKS / 64;  // 1 KiB glds pieces per tile
+  static constexpr int PPW = (PIECES + WAVES - 1) / WAVES;  // pieces per wave (last ones may be idle)
+  static constexpr int SWZ_MASK = (CHUNKS % 16 == 0) ? 15 : 7;
+  static constexpr int SMEM = 4 * TILE_BYTES;   // {K, V} x 2 buffers
+  static_assert(DH % 64 == 0, "dim_head must be a multiple of 64");
+};
+
+template <int DH>
+__device__ __forceinline__ int swz_chunk(int chunk, int row) {
+  constexpr int MASK = AttnCfg<DH>::SWZ_MASK;
+  return (chunk & ~MASK) | ((chunk ^ ((row & 7) << 1)) & MASK);
+}
+
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+                                                          int T, int heads, float scale_log2e, int qblocks) {
+  using C = AttnCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fq = lane >> 4, l15 = lane & 15;
+
+  int bid = blockIdx.x;
+  const int qb = bid % qblocks; bid /= qblocks;
+  const int h = bid % heads;
+  const int b = bid / heads;
+  const int64_t inner = (int64_t)heads * DH, ld = 3 * inner;
+  const unsigned short* qbase = qkv + (int64_t)b * T * ld + (int64_t)h * DH;
+  const unsigned short* kbase = qbase + inner;
+  const unsigned short* vbase = qbase + 2 * inner;
+
+  // ---- Q^T fragments: lane (q = l15, fq) holds Q[q][32 ks + 8 fq .. +7] for every k-step ----
+  const int q0 = qb * 128 + wave * 16;
+  const int qrow = (q0 + l15 < T) ? q0 + l15 : T - 1;
+  bf16x8_t qf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) qf[ks] = *(const bf16x8_t*)(qbase + (int64_t)qrow * ld + ks * 32 + fq * 8);
+
+  // ---- staging plan: piece i of this wave covers linear chunks [(wave + 8 i)*64, +64) of a tile.  The per-lane
+  // part of the source address is a 32-bit element offset fixed for the whole kernel; the tile's first key
+  // goes into the (scalar) base pointer. ----
+  int st_row[C::PPW], st_src[C::PPW], st_off[C::PPW];
+#pragma unroll
+  for (int i = 0; i < C::PPW; ++i) {
+    const int p = (wave + C::WAVES * i) * 64 + lane;
+    st_row[i] = p / C::CHUNKS;
+    st_src[i] = swz_chunk<DH>(p % C::CHUNKS, st_row[i]) * 8;  // element offset of the SOURCE chunk inside the row
+    st_off[i] = st_row[i] * (int)ld + st_src[i];
+  }
+  auto stage = [&](int buf, int key0) {
+    char* kdst = smem + buf * 2 * C::TILE_BYTES;
+    const unsigned short* kb = kbase + (int64_t)key0 * ld;
+    const unsigned short* vb = vbase + (int64_t)key0 * ld;
+    const bool full = key0 + C::KV <= T;
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) {
+      const int piece = wave + C::WAVES * i;  // wave-uniform
+      if (piece < C::PIECES) {
+        int off = st_off[i];
+        if (!full) {  // tail keys re-read a valid row; they are masked to -inf below
+          const int row = (key0 + st_row[i] < T) ? st_row[i] : T - 1 - key0;
+          off = row * (int)ld + st_src[i];
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), (lptr_t)(kdst + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), (lptr_t)(kdst + C::TILE_BYTES + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- per-lane LDS read offsets.  The XOR swizzle only permutes chunks inside a segment of SEG chunks, so an
+  // address is (one of a few per-lane registers) + (a compile-time offset that folds into the ds_read immediate) ----
+  constexpr int SEG = C::SWZ_MASK + 1;
+  // K row read (A operand of S^T): row = key = l15 (+16 for the second key tile: same row & 7), chunk = 4 ks + fq
+  constexpr int KRD = SEG / 4;
+  int k_rd[KRD];
+#pragma unroll
+  for (int i = 0; i < KRD; ++i) k_rd[i] = l15 * C::ROWB + swz_chunk<DH>(4 * i + fq, l15) * 16;
+  // V transposed read (A operand of O^T): lane i of a 16-lane group supplies row (i >> 2) of a 4-key block,
+  // columns 4 (i & 3) .. +3 of the 16-column d-tile; group fq reads key block 4 fq (and 16 + 4 fq).
+  const int tq = l15 >> 2, tp = l15 & 3;
+  constexpr int VRD = SEG / 2;
+  int v_rd[VRD];
+#pragma unroll
+  for (int i = 0; i < VRD; ++i) {
+    const int row = 4 * fq + tq;
+    v_rd[i] = row * C::ROWB + swz_chunk<DH>(2 * i + (tp >> 1), row) * 16 + (tp & 1) * 8;
+  }
+
+  f32x4_t o[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (T + C::KV - 1) / C::KV;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) stage(cur ^ 1, (t + 1) * C::KV);
+    const char* kt = smem + cur * 2 * C::TILE_BYTES;
+    const char* vt = kt + C::TILE_BYTES;
+
+    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: two key tiles (keys 0-15, 16-31) share each Q fragment ----
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int off = k_rd[ks % KRD] + (ks / KRD) * SEG * 16;
+      const bf16x8_t ka = *(const bf16x8_t*)(kt + off);
+      const bf16x8_t kb2 = *(const bf16x8_t*)(kt + off + 16 * C::ROWB);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb2, qf[ks], s1, 0, 0, 0);
+    }
+    // accumulator map: s0[r] = S^T[key = 4 fq + r][q = l15], s1[r] = S^T[key = 16 + 4 fq + r][q]
+    const int key_base = t * C::KV + 4 * fq;
+    float sv[8];
+    float pmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sv[r] = (key_base + r < T) ? s0[r] * scale_log2e : -INFINITY;
+      sv[4 + r] = (key_base + 16 + r < T) ? s1[r] * scale_log2e : -INFINITY;
+      pmax = fmaxf(pmax, fmaxf(sv[r], sv[4 + r]));
+    }
+    // the other three 16-lane groups hold the other keys of this query
+    pmax = fmaxf(pmax, __shfl_xor(pmax, 16, 64));
+    pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+    // deferred max: rescale only when some row's maximum moved by more than 2^8
+    if (!__all(pmax - m_run <= 8.0f)) {
+      const float m_new = fmaxf(m_run, pmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    }
+    bf16x8_t pf;
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p = __builtin_amdgcn_exp2f(sv[j] - m_run);
+      psum += p;
+      pf[j] = (short)f32_to_bf16(p);
+    }
+    l_run += psum;
+
+    // ---- O^T[d][q] += sum_key V[key][d] P^T[key][q] ----
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      // d-tile dt covers columns 16 dt .. +15 = chunks 2 dt, 2 dt + 1
+      const int off = v_rd[dt % VRD] + (dt / VRD) * SEG * 16;
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vt + off));
+      const s16x4_t hi =
+          __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vt + off + 16 * C::ROWB));
+      bf16x8_t vf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- normalise and write: O^T[d = 16 dt + 4 fq + r][q = l15] -> out[q][h*DH + d], 4 consecutive d (8 bytes) per store ----
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l15;
+  if (q < T) {
+    unsigned short* orow = out + ((int64_t)b * T + q) * inner + (int64_t)h * DH + 4 * fq;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      u16x4_t pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = f32_to_bf16(o[dt][e] * inv);
+      *(u16x4_t*)(orow + 16 * dt) = pk;
+    }
+  }
+}
+
+template <int DH>
+int launch_attn(const uint16_t* qkv, int64_t B, int64_t T, int heads, float scale, uint16_t* out, hipStream_t s) {
+  using C = AttnCfg<DH>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr_done = true;
+  }
+  const int qblocks = (int)((T + 127) / 128);
+  const int64_t nblocks = B * heads * qblocks;
+  if (nblocks >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: grid too large"); return -1; }
+  if (T * 3 * (int64_t)heads * DH >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: sequence too long for 32-bit offsets"); return -1; }
+  hipLaunchKernelGGL(attn_fwd_kernel<DH>, dim3((unsigned)nblocks), dim3(512), C::SMEM, s, qkv, out, (int)T, heads,
+                     scale * 1.4426950408889634f, qblocks);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// returns 1 if a fused kernel exists for this head size, else 0 (caller falls back to the 3-kernel path)
+int tribe_internal_attention_fused_supported(int dim_head) {
+  return dim_head == 64 || dim_head == 128 || dim_head == 192 || dim_head == 384;
+}
+
+int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
+                                   hipStream_t s) {
+  switch (dim_head) {
+    case 64: return launch_attn<64>(qkv, B, T, heads, scale, out, s);
+    case 128: return launch_attn<128>(qkv, B, T, heads, scale, out, s);
+    case 192: return launch_attn<192>(qkv, B, T, heads, scale, out, s);
+    case 384: return launch_attn<384>(qkv, B, T, heads, scale, out, s);
+    default: tribe_set_error("fused attention: unsupported dim_head %d", dim_head); return -1;
+  }
+}

@@ -9,6 +9,16 @@ int tribe_internal_softmax(const float* S, int64_t R, int64_t T, int64_t ld_s, u
                            hipStream_t stream);
 int tribe_internal_transpose_v(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, uint16_t* vt, int64_t T_pad,
                                hipStream_t stream);
+int tribe_internal_attention_fused_supported(int dim_head);
+int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
+                                   hipStream_t s);
+
+static int g_attn_mode = 0;  // 0 = fused kernel when the head size has one, 1 = always the 3-kernel (materialised) path
+extern "C" int tribe_attention_set_mode(int32_t mode) {
+  TRIBE_REQUIRE(mode == 0 || mode == 1, "tribe_attention_set_mode: mode must be 0 (auto) or 1 (materialised scores)");
+  g_attn_mode = mode;
+  return 0;
+}
 
 namespace {
 
@@ -82,6 +92,8 @@ extern "C" int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, in
   TRIBE_REQUIRE(dim_head % 64 == 0, "tribe_attention_fwd: dim_head=%d must be a multiple of 64", dim_head);
   TRIBE_REQUIRE(workspace_bytes >= tribe_attention_workspace_bytes(B, T, heads, dim_head), "tribe_attention_fwd: workspace too small");
   TRIBE_REQUIRE(((uintptr_t)workspace % 256) == 0, "tribe_attention_fwd: workspace must be 256-byte aligned");
+  if (g_attn_mode == 0 && tribe_internal_attention_fused_supported(dim_head))
+    return tribe_internal_attention_fused(qkv, B, T, heads, dim_head, scale, out, (hipStream_t)stream);
   const AttnPlan p = attn_plan(B, T, heads, dim_head);
   const int64_t inner = (int64_t)heads * dim_head, Tp = p.T_pad;
   float* S = (float*)workspace;

@@ -81,6 +81,7 @@ SIGNATURES = {
     "tribe_scalenorm_fwd": (C.c_int, [vp, i64, i64, vp, f32, f32, vp, i32, vp]),
     "tribe_rotary_fwd": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, vp, i32, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),
+    "tribe_attention_set_mode": (C.c_int, [i32]),
     "tribe_attention_fwd": (C.c_int, [vp, i64, i64, i32, i32, f32, vp, vp, sz, vp]),
     "tribe_encoder_workspace_bytes": (sz, [C.POINTER(EncoderDesc)]),
     "tribe_encoder_fwd": (C.c_int, [C.POINTER(EncoderDesc), vp, vp, i32, vp, sz, vp]),

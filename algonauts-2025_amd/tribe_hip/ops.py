@@ -198,6 +198,11 @@ def rotary_(qkv: torch.Tensor, T: int, heads: int, dim_head: int, rot_dim: int, 
     return qkv
 
 
+def attention_set_mode(mode: int) -> None:
+    """0 = fused kernel (default), 1 = materialised-scores path (cross-check)."""
+    check(lib().tribe_attention_set_mode(mode), "tribe_attention_set_mode")
+
+
 def attention(qkv: torch.Tensor, B: int, T: int, heads: int, dim_head: int, scale: float) -> torch.Tensor:
     _cuda(qkv, torch.bfloat16, "qkv")
     if qkv.numel() != B * T * 3 * heads * dim_head:

@@ -128,6 +128,9 @@ int tribe_rotary_fwd(uint16_t* qkv, int64_t rows, int64_t T, int32_t heads, int3
                      const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream);
 /* softmax(q k^T * scale) v for all (batch, head); qkv as above; out bf16 [rows, heads*dim_head] */
 size_t tribe_attention_workspace_bytes(int64_t B, int64_t T, int32_t heads, int32_t dim_head);
+/* 0 (default): fused flash-style kernel for dim_head in {64,128,192,384}, else the materialised path;
+ * 1: always materialise scores (QK^T GEMM -> f32 softmax -> PV GEMM), kept as a cross-check */
+int tribe_attention_set_mode(int32_t mode);
 int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, int32_t heads, int32_t dim_head, float scale,
                         uint16_t* out, void* workspace, size_t workspace_bytes, void* stream);
 

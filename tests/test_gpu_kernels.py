@@ -161,12 +161,20 @@ def test_rotary(ops, interleaved):
     torch.testing.assert_close(got[:, :, 2], v, rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("B,T,h,d", [(2, 70, 4, 64), (1, 298, 2, 192), (3, 128, 8, 384)])
-def test_attention(ops, B, T, h, d):
+@pytest.mark.parametrize("mode", [0, 1])  # 0 = fused flash-style kernel, 1 = materialised scores (3 kernels)
+@pytest.mark.parametrize("B,T,h,d", [(2, 70, 4, 64), (1, 298, 2, 192), (3, 128, 8, 384), (2, 1024, 2, 384), (1, 33, 1, 128)])
+def test_attention(ops, B, T, h, d, mode):
     g = torch.Generator().manual_seed(9)
     qkv = bf(torch.randn(B * T, 3 * h * d, generator=g))
+    if T == 1024:  # force the deferred-max rescale branch late in the key loop: one huge score at key 900 for query 5
+        qkv.view(B, T, 3, h, d)[0, 5, 0, 0] *= 6.0
+        qkv.view(B, T, 3, h, d)[0, 900, 1, 0] = bf(qkv.view(B, T, 3, h, d)[0, 5, 0, 0] * 0.5)
     scale = d**-0.5
-    out = ops.attention(_dev(qkv).bfloat16(), B, T, h, d, scale).float().cpu()
+    ops.attention_set_mode(mode)
+    try:
+        out = ops.attention(_dev(qkv).bfloat16(), B, T, h, d, scale).float().cpu()
+    finally:
+        ops.attention_set_mode(0)
     q, k, v = (t.transpose(1, 2) for t in qkv.view(B, T, 3, h, d).unbind(2))
     sim = torch.einsum("bhid,bhjd->bhij", q, k) * scale
     want = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).transpose(1, 2).reshape(B * T, h * d)
