@@ -41,8 +41,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int64_t z = blockIdx.y;
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int64_t z = blockIdx.y;

@@ -17,6 +17,35 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// tile id -> (tm, tn): the XCD remap first gives every XCD one contiguous run of ids; inside a run ids walk
+// bands of GM = 4 tile rows column by column, so the ~32 workgroups an XCD runs at once form a 4 x 8 patch
+// that shares 4 A panels and 8 B panels in that XCD's L2 (instead of 1 + 32 with a plain row-major walk).
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  constexpr int GM = 4;
+  const int tile = xcd_remap(bid, tiles_m * tiles_n);
+  const int band = tile / (GM * tiles_n);
+  const int first_m = band * GM;
+  const int gm = (tiles_m - first_m < GM) ? tiles_m - first_m : GM;
+  const int r = tile - band * GM * tiles_n;
+  tn = r / gm;
+  tm = first_m + (r - tn * gm);
+}
+
+// GELU(v) = v * Phi(v) with Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|erf error| <= 1.5e-7) in its
+// cancellation-free form: q = 0.5 * poly(t) * exp(-x^2), x = |v| / sqrt(2), t = 1 / (1 + p x); Phi = v < 0 ? q : 1 - q.
+// ~14 VALU + v_exp + v_rcp per element instead of the ~40-instruction branchy libm erff; used where the result is
+// rounded to bf16 anyway (relative error there 2^-9 >> 1.5e-7).
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float q = 0.5f * poly * t * __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+  return v * (v < 0.f ? q : 1.0f - q);
+}
+
 // quad-lane exchanges as DPP moves (no LDS traffic): lane i <- lane i^1 / i^2 within each group of 4
 __device__ __forceinline__ float quad_xor1(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -86,7 +115,7 @@ __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const 
     }
     if (g.act == TRIBE_ACT_GELU) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
+      for (int k = 0; k < 4; ++k) v[k] = OUT_BF16 ? gelu_fast(v[k]) : gelu_erf(v[k]);
     }
     if (c.res) {
       const float4 r = *(const float4*)(c.res + m * g.ldres + n);
@@ -120,7 +149,7 @@ __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const 
     if (n + k >= g.N) break;
     float x = v[k];
     if (g.bias_mode == TRIBE_BIAS_COL) x += c.bias[n + k];
-    if (g.act == TRIBE_ACT_GELU) x = gelu_erf(x);
+    if (g.act == TRIBE_ACT_GELU) x = OUT_BF16 ? gelu_fast(x) : gelu_erf(x);
     if (c.res) {
       const float r = c.res[m * g.ldres + n + k];
       x += g.res_scale ? r * g.res_scale[n + k] : r;
