@@ -3,12 +3,16 @@
 // Two tile configurations share one operator epilogue (gemm_common.h):
 //  * 256x256x64, 512 threads (8 waves as 2x4, 128x64 per wave, 8x4 v_mfma_f32_16x16x32_bf16
 //    accumulators), 128 KiB LDS = 2 K-tile buffers.  Operands go HBM/L2 -> LDS with
-//    global_load_lds_dwordx4 (no VGPR round trip) in "half-tiles" of 128 rows, one half-tile per
-//    phase, four phases per K-tile (one C quadrant = 16 MFMAs per wave each).  Loads stay in flight
-//    across the raw s_barriers behind a COUNTED s_waitcnt vmcnt(6): three half-tiles (of K-tile t+2)
-//    are always outstanding while K-tile t computes (the 8-phase schedule of cdna_hip_programming.md
-//    section 5, re-derived: a half-tile is the set of rows read in ONE phase, so it can be restaged
-//    one phase after that phase).
+//    global_load_lds_dwordx4 (no VGPR round trip) in "half-tiles" of 128 rows.  A half-tile is the set
+//    of tile rows whose fragments are read in ONE phase, so it can be restaged right after that phase:
+//    per K-tile there are two phases (two C quadrants = 32 MFMAs per wave each); phase B restages three
+//    half-tiles of K-tile t+2, phase A the fourth, and every phase ends its read slot with a COUNTED
+//    s_waitcnt vmcnt(8) -- four half-tiles (80 KiB per CU) stay in flight across the raw s_barriers,
+//    each with two full phases of slack (the counted-vmcnt schedule of cdna_hip_programming.md
+//    section 5, re-derived for 2 LDS buffers).  The two wave groups wr = 0 / 1 (= the two waves of each
+//    SIMD) run one barrier apart, so one group's LDS-read slot overlaps the other group's MFMA slot.
+//    In-kernel stamps (scripts/gemm_stamps.py): MFMA cluster 42 %, LDS reads 18 %, stage + vmcnt 21 %,
+//    barriers 18 % of a wave's K-loop time; matrix pipe ~78 % busy inside the loop.
 //  * 128x128x64, 256 threads (4 waves, 64x64 per wave), double buffered, one vmcnt(0)+barrier per
 //    K-tile: used when M or N is too small to fill 256-wide tiles.
 // The LDS image is lane-linear (a glds requirement), so the bank-conflict swizzle
@@ -31,6 +35,22 @@ constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // 128 KiB
 }  // namespace big
 
 #define TRIBE_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// Diagnostic build only (-DTRIBE_GEMM_STAMPS): s_memtime stamps around the slots of the K loop, summed per wave and
+// written to a side buffer that no other code reads (its pointer rides in desc.gadd_index while desc.gadd == NULL).
+// Never quote the run time of this build; read the SHARES.
+#ifdef TRIBE_GEMM_STAMPS
+#define TRIBE_STAMP(var)                                                                  \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#define TRIBE_STAMP_ACC(slot, t_from, t_to) stamp_acc[slot] += (t_to) - (t_from)
+#else
+#define TRIBE_STAMP(var) do { } while (0)
+#define TRIBE_STAMP_ACC(slot, t_from, t_to) do { } while (0)
+#endif
 
 template <int OUT_BF16, int ROLE>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
@@ -119,16 +139,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
     acc[(MH) * 4 + i][(NH) * 2 + j] =                                                          \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], FB[j][1], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
   }
+// The fragment reads are retired BEFORE the barrier: the two wave groups (wr = 0 / 1 = the two waves of every
+// SIMD) run one barrier apart, so while one group sits in this wait the other group's MFMA cluster owns the
+// matrix pipe, and at every barrier all LDS reads issued so far are complete (restaging is then hazard-free).
 #define TRIBE_PHASE_SYNC_MMA(MH, NH, FB)        \
-  __builtin_amdgcn_s_barrier();                 \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0);            \
+  __builtin_amdgcn_s_barrier();                 \
   __builtin_amdgcn_s_setprio(1);                \
   TRIBE_MMA(MH, NH, FB)                         \
   __builtin_amdgcn_s_setprio(0);                \
   __builtin_amdgcn_s_barrier();
 
+#define TRIBE_PHASE_SYNC_MMA2(MH0, NH0, FB0, MH1, NH1, FB1) \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  TRIBE_STAMP(ts2);                                        \
+  __builtin_amdgcn_s_barrier();                            \
+  TRIBE_STAMP(ts3);                                        \
+  __builtin_amdgcn_s_setprio(1);                           \
+  TRIBE_MMA(MH0, NH0, FB0)                                 \
+  TRIBE_MMA(MH1, NH1, FB1)                                 \
+  __builtin_amdgcn_s_setprio(0);                           \
+  TRIBE_STAMP(ts4);                                        \
+  __builtin_amdgcn_s_barrier();                            \
+  TRIBE_STAMP(ts5);                                        \
+  TRIBE_STAMP_ACC(1, ts1, ts2); TRIBE_STAMP_ACC(2, ts2, ts3); TRIBE_STAMP_ACC(3, ts3, ts4); TRIBE_STAMP_ACC(4, ts4, ts5);
+
   const int nk = (int)(g.K / BK);
+#ifdef TRIBE_GEMM_STAMPS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+  unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0};  // 0 LDS reads, 1 stage + vmcnt wait, 2 barrier 1, 3 MFMA cluster, 4 barrier 2
+#endif
 
   // ---- prologue: K-tile 0 completely, K-tile 1 minus its last half-tile ----
   stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
@@ -139,32 +181,51 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
     TRIBE_WAIT_VMCNT(0);
   }
   __builtin_amdgcn_s_barrier();
+  // stagger: group wr = 1 runs one barrier behind group wr = 0 for the whole K loop (LDS-read slots of one
+  // group overlap MFMA slots of the other); group 0 pays the matching barrier after the loop.
+  if (wr == 1) __builtin_amdgcn_s_barrier();
 
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     const char* base = smem + cur * BUF_BYTES;
-    // phase 1: quadrant (m-half 0, n-half 0); restage: last half-tile (A half 1) of K-tile t+1
+    // ---- phase A: quadrants (0,0) and (0,1): 16 fragment reads, 32 MFMAs.  Restage: the last half-tile (A half 1)
+    // of K-tile t+1 into the other buffer (its previous content was last read in phase B of K-tile t-1).
+    TRIBE_STAMP(ts0);
     TRIBE_LDS_B(base, 0, fb0)
-    TRIBE_LDS_A(base, 0)
-    if (t + 1 < nk) stage(3, cur ^ 1, t + 1);
-    TRIBE_PHASE_SYNC_MMA(0, 0, fb0)
-    // phase 2: (0, 1); A half 0 of THIS buffer was last read in phase 1 -> restage it for K-tile t+2
     TRIBE_LDS_B(base, 1, fb1)
-    if (t + 2 < nk) stage(0, cur, t + 2);
-    TRIBE_PHASE_SYNC_MMA(0, 1, fb1)
-    // phase 3: (1, 1); B half 0 was last read in phase 1
+    TRIBE_LDS_A(base, 0)
+    TRIBE_STAMP(ts1);
+    TRIBE_STAMP_ACC(0, ts0, ts1);
+    // retire A half 1 of THIS K-tile (read in phase B): behind it in the queue are the three half-tiles of
+    // K-tile t+1 issued in the previous phase B and the one issued just now
+    if (t + 1 < nk) { stage(3, cur ^ 1, t + 1); TRIBE_WAIT_VMCNT(8); } else { TRIBE_WAIT_VMCNT(0); }
+    TRIBE_PHASE_SYNC_MMA2(0, 0, fb0, 0, 1, fb1)
+    // ---- phase B: quadrants (1,1) and (1,0): 8 fragment reads, 32 MFMAs.  A half 0 and both B halves of THIS
+    // buffer were last read in phase A -> restage them for K-tile t+2.
+    TRIBE_STAMP(ts0);
     TRIBE_LDS_A(base, 1)
-    if (t + 2 < nk) stage(1, cur, t + 2);
-    TRIBE_PHASE_SYNC_MMA(1, 1, fb1)
-    // phase 4: (1, 0) from registers only; B half 1 was last read in phase 2.  Then retire K-tile t+1:
-    // everything issued before the three half-tiles of K-tile t+2 must have landed.
-    if (t + 2 < nk) { stage(2, cur, t + 2); TRIBE_WAIT_VMCNT(6); } else { TRIBE_WAIT_VMCNT(0); }
-    TRIBE_PHASE_SYNC_MMA(1, 0, fb0)
+    TRIBE_STAMP(ts1);
+    TRIBE_STAMP_ACC(0, ts0, ts1);
+    if (t + 2 < nk) {
+      stage(0, cur, t + 2); stage(1, cur, t + 2); stage(2, cur, t + 2);
+      TRIBE_WAIT_VMCNT(8);  // retire A0/B0/B1 of K-tile t+1; behind them: A1(t+1) and the three just issued
+    } else if (t + 1 < nk) {
+      TRIBE_WAIT_VMCNT(2);  // behind them: only A1(t+1)
+    }
+    TRIBE_PHASE_SYNC_MMA2(1, 1, fb1, 1, 0, fb0)
   }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#ifdef TRIBE_GEMM_STAMPS
+  if (g.gadd == nullptr && g.gadd_index != nullptr && lane == 0 && blockIdx.y == 0) {
+    unsigned long long* dbg = (unsigned long long*)g.gadd_index + ((size_t)blockIdx.x * 8 + wave) * 8;
+    for (int i = 0; i < 5; ++i) dbg[i] = stamp_acc[i];
+  }
+#endif
 #undef TRIBE_LDS_A
 #undef TRIBE_LDS_B
 #undef TRIBE_MMA
 #undef TRIBE_PHASE_SYNC_MMA
+#undef TRIBE_PHASE_SYNC_MMA2
 
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
 #pragma unroll
