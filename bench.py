@@ -110,6 +110,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    from algonauts2025.distributed import gather_predictions
     from tribe_hip import ops
 
     B = 4 * args.repeats
@@ -129,7 +130,7 @@ def main() -> None:
         if gather:
             if len(pending) == 2:
                 pending.pop(0).wait()
-            pending.append(dist.all_gather_into_tensor(gather_bufs[i & 1], pred, async_op=True))
+            pending.append(gather_predictions(pred, out=gather_bufs[i & 1], async_op=True)[1])
         return pred
 
     pending: list = []

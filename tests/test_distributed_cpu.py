@@ -1,0 +1,92 @@
+"""CPU, world_size 2, gloo: the N > 1 host path (sequence sharding, all-gather of predictions, all-reduce of the
+Pearson sufficient statistics) gives exactly the single-process result.  The arithmetic that runs on the GPU in
+production (predictions, statistics) is produced here by the CPU oracle -- only the distribution logic is under test."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tribe_ref
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, q):
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "algonauts-2025_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from algonauts2025 import distributed as D
+        from modeling_utils.metrics.base import _PearsonState
+
+        torch.manual_seed(0)
+        B, V, T = 6, 11, 20
+        g = torch.Generator().manual_seed(5)
+        pred_all = torch.randn(B, V, T, generator=g)
+        true_all = 0.3 * pred_all + torch.randn(B, V, T, generator=g)
+        data = {"pred": pred_all, "fmri": true_all, "subject_id": (torch.arange(B) % 4).view(B, 1)}
+        mine = D.shard_batch(data, rank, world)
+        assert mine["pred"].shape[0] == B // world
+        # (1) all-gather of predictions, restored to the original order
+        buf, work = D.gather_predictions(mine["pred"], async_op=True)
+        work.wait()
+        restored = buf[torch.tensor(D.unshard_order(B, world))]
+        ok_gather = torch.equal(restored, pred_all)
+        # (2) all-reduce of the sufficient statistics == statistics of the whole data set
+        local = tribe_ref.pearson_stats(tribe_ref.flatten_bt(mine["pred"]), tribe_ref.flatten_bt(mine["fmri"]))  # [5, V]
+        stats = torch.zeros(1, V, 6, dtype=torch.float64)
+        stats[0, :, :5] = local.t()
+        stats[0, :, 5] = mine["pred"].shape[0] * T
+        state = _PearsonState(V)
+        state.stats = stats
+        state.sync()
+        full = tribe_ref.pearson_stats(tribe_ref.flatten_bt(pred_all), tribe_ref.flatten_bt(true_all))
+        ok_stats = torch.allclose(state.stats[0, :, :5].t(), full, rtol=1e-12) and bool((state.stats[0, :, 5] == B * T).all())
+        r = tribe_ref.pearson_from_stats(state.stats[0, :, :5].t(), B * T).numpy()
+        ref = tribe_ref.scipy_pearson_columns(tribe_ref.flatten_bt(pred_all).numpy(), tribe_ref.flatten_bt(true_all).numpy())
+        ok_r = bool(np.abs(r - ref).max() < 2e-6)
+        q.put((rank, ok_gather, ok_stats, ok_r))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_gather_and_stats():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1]
+    assert all(all(r[1:]) for r in results), results
+
+
+def test_shard_indices_cover_and_partition():
+    from algonauts2025 import distributed as D
+
+    for n in (1, 4, 7, 16):
+        for g in (1, 2, 3, 8):
+            parts = [D.shard_indices(n, r, g) for r in range(g)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+    with pytest.raises(ValueError):
+        D.shard_indices(4, 2, 2)
+    inv = D.unshard_order(8, 4)
+    order = [i for r in range(4) for i in D.shard_indices(8, r, 4)]
+    assert [order[p] for p in inv] == list(range(8))
