@@ -43,6 +43,11 @@ def gather_predictions(pred: torch.Tensor, out: torch.Tensor | None = None, asyn
         return pred, None
     if out is None:
         out = torch.empty((ws * pred.shape[0],) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
+    if dist.get_backend(group) == "gloo" and pred.is_cuda:
+        # rehearsal path (several ranks on one GPU): gloo has no device-side all_gather_into_tensor
+        chunks = list(out.chunk(ws, dim=0))
+        work = dist.all_gather(chunks, pred.contiguous(), group=group, async_op=async_op)
+        return out, work
     work = dist.all_gather_into_tensor(out, pred.contiguous(), group=group, async_op=async_op)
     return out, work
 

@@ -94,6 +94,8 @@ def main() -> None:
     ap.add_argument("--repeats", type=int, default=4, help="R: stacked passes of the 4-subject batch per rank (B = 4R)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of predictions (N > 1)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal "
+                    "of the multi-process path when fewer GPUs than ranks are visible)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,11 +106,14 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from algonauts2025.distributed import gather_predictions
     from tribe_hip import ops
