@@ -50,30 +50,43 @@ __device__ __forceinline__ int swz_chunk(int chunk, int row) {
   return (chunk & ~MASK) | ((chunk ^ ((row & 7) << 1)) & MASK);
 }
 
-template <int DH>
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
-                                                          int T, int heads, float scale_log2e, int qblocks) {
+struct AttnArgs {
+  const unsigned short* q; const unsigned short* k; const unsigned short* v;
+  unsigned short* out;
+  int64_t ld_q, ld_kv, ld_out;
+  int T, heads_q, group;  // group = heads_q / heads_kv
+  float scale_log2e;
+  int qblocks;
+};
+
+// CAUSAL: key <= query (HF LlamaAttention.is_causal, modeling_llama.py); a wave skips key tiles that lie entirely
+// above its 16 query rows, the workgroup stops at the last tile its 128 rows can see.
+template <int DH, int CAUSAL>
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fq = lane >> 4, l15 = lane & 15;
 
+  const int T = a.T;
+  const float scale_log2e = a.scale_log2e;
   int bid = blockIdx.x;
-  const int qb = bid % qblocks; bid /= qblocks;
-  const int h = bid % heads;
-  const int b = bid / heads;
-  const int64_t inner = (int64_t)heads * DH, ld = 3 * inner;
-  const unsigned short* qbase = qkv + (int64_t)b * T * ld + (int64_t)h * DH;
-  const unsigned short* kbase = qbase + inner;
-  const unsigned short* vbase = qbase + 2 * inner;
+  const int qb = bid % a.qblocks; bid /= a.qblocks;
+  const int h = bid % a.heads_q;
+  const int b = bid / a.heads_q;
+  const int hk = h / a.group;
+  const int64_t ld = a.ld_kv;
+  const unsigned short* qbase = a.q + (int64_t)b * T * a.ld_q + (int64_t)h * DH;
+  const unsigned short* kbase = a.k + (int64_t)b * T * ld + (int64_t)hk * DH;
+  const unsigned short* vbase = a.v + (int64_t)b * T * ld + (int64_t)hk * DH;
 
   // ---- Q^T fragments: lane (q = l15, fq) holds Q[q][32 ks + 8 fq .. +7] for every k-step ----
   const int q0 = qb * 128 + wave * 16;
   const int qrow = (q0 + l15 < T) ? q0 + l15 : T - 1;
   bf16x8_t qf[C::KS];
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) qf[ks] = *(const bf16x8_t*)(qbase + (int64_t)qrow * ld + ks * 32 + fq * 8);
+  for (int ks = 0; ks < C::KS; ++ks) qf[ks] = *(const bf16x8_t*)(qbase + (int64_t)qrow * a.ld_q + ks * 32 + fq * 8);
 
   // ---- staging plan: piece i of this wave covers linear chunks [(wave + 8 i)*64, +64) of a tile.  The per-lane
   // part of the source address is a 32-bit element offset fixed for the whole kernel; the tile's first key
@@ -130,7 +143,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* 
   for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (T + C::KV - 1) / C::KV;
+  int kv_end = T;  // keys this workgroup can see
+  if (CAUSAL) { const int last_q = qb * 128 + 127; kv_end = (last_q + 1 < T) ? last_q + 1 : T; }
+  const int ntiles = (kv_end + C::KV - 1) / C::KV;
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -140,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* 
     if (t + 1 < ntiles) stage(cur ^ 1, (t + 1) * C::KV);
     const char* kt = smem + cur * 2 * C::TILE_BYTES;
     const char* vt = kt + C::TILE_BYTES;
+    if (!CAUSAL || t * C::KV <= q0 + 15) {  // wave-uniform: some key of this tile is visible to some row of this wave
 
     // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: two key tiles (keys 0-15, 16-31) share each Q fragment ----
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -157,8 +173,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* 
     float pmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      sv[r] = (key_base + r < T) ? s0[r] * scale_log2e : -INFINITY;
-      sv[4 + r] = (key_base + 16 + r < T) ? s1[r] * scale_log2e : -INFINITY;
+      const int lim = CAUSAL ? ((q0 + l15 + 1 < T) ? q0 + l15 + 1 : T) : T;  // first masked key for this lane's query
+      sv[r] = (key_base + r < lim) ? s0[r] * scale_log2e : -INFINITY;
+      sv[4 + r] = (key_base + 16 + r < lim) ? s1[r] * scale_log2e : -INFINITY;
       pmax = fmaxf(pmax, fmaxf(sv[r], sv[4 + r]));
     }
     // the other three 16-lane groups hold the other keys of this query
@@ -198,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* 
       for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
       o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
     }
+    }  // visible tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* 
   const float inv = 1.0f / l_tot;
   const int q = q0 + l15;
   if (q < T) {
-    unsigned short* orow = out + ((int64_t)b * T + q) * inner + (int64_t)h * DH + 4 * fq;
+    unsigned short* orow = a.out + ((int64_t)b * T + q) * a.ld_out + (int64_t)h * DH + 4 * fq;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       u16x4_t pk;
@@ -219,22 +237,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const unsigned short* 
   }
 }
 
-template <int DH>
-int launch_attn(const uint16_t* qkv, int64_t B, int64_t T, int heads, float scale, uint16_t* out, hipStream_t s) {
+template <int DH, int CAUSAL>
+int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
   using C = AttnCfg<DH>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     attr_done = true;
   }
-  const int qblocks = (int)((T + 127) / 128);
-  const int64_t nblocks = B * heads * qblocks;
+  const int64_t nblocks = B * a.heads_q * a.qblocks;
   if (nblocks >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: grid too large"); return -1; }
-  if (T * 3 * (int64_t)heads * DH >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: sequence too long for 32-bit offsets"); return -1; }
-  hipLaunchKernelGGL(attn_fwd_kernel<DH>, dim3((unsigned)nblocks), dim3(512), C::SMEM, s, qkv, out, (int)T, heads,
-                     scale * 1.4426950408889634f, qblocks);
+  if ((int64_t)a.T * a.ld_kv >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: sequence too long for 32-bit offsets"); return -1; }
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL>), dim3((unsigned)nblocks), dim3(512), C::SMEM, s, a);
   TRIBE_LAUNCH_CHECK();
   return 0;
+}
+
+template <int DH>
+int launch_attn_dh(const AttnArgs& a, int64_t B, int causal, hipStream_t s) {
+  return causal ? launch_attn<DH, 1>(a, B, s) : launch_attn<DH, 0>(a, B, s);
 }
 
 }  // namespace
@@ -244,13 +265,38 @@ int tribe_internal_attention_fused_supported(int dim_head) {
   return dim_head == 64 || dim_head == 128 || dim_head == 192 || dim_head == 384;
 }
 
+extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* stream) {
+  TRIBE_REQUIRE(d && d->q && d->k && d->v && d->out, "tribe_attention_fwd_ex: null pointer");
+  TRIBE_REQUIRE(d->B > 0 && d->T > 0 && d->heads_q > 0 && d->heads_kv > 0 && d->heads_q % d->heads_kv == 0,
+                "tribe_attention_fwd_ex: bad shape (B=%lld T=%lld heads %d/%d)", (long long)d->B, (long long)d->T, d->heads_q, d->heads_kv);
+  TRIBE_REQUIRE(tribe_internal_attention_fused_supported(d->dim_head), "tribe_attention_fwd_ex: dim_head=%d not in {64,128,192,384}",
+                d->dim_head);
+  TRIBE_REQUIRE(d->ld_k == d->ld_v, "tribe_attention_fwd_ex: k and v must share their row stride");
+  TRIBE_REQUIRE(d->ld_q % 8 == 0 && d->ld_k % 8 == 0 && d->ld_out % 4 == 0 && ((uintptr_t)d->q % 16) == 0 && ((uintptr_t)d->k % 16) == 0 &&
+                    ((uintptr_t)d->v % 16) == 0 && ((uintptr_t)d->out % 8) == 0,
+                "tribe_attention_fwd_ex: operands must be 16-byte aligned with row strides that are multiples of 8");
+  AttnArgs a;
+  a.q = d->q; a.k = d->k; a.v = d->v; a.out = d->out;
+  a.ld_q = d->ld_q; a.ld_kv = d->ld_k; a.ld_out = d->ld_out;
+  a.T = (int)d->T; a.heads_q = d->heads_q; a.group = d->heads_q / d->heads_kv;
+  a.scale_log2e = d->scale * 1.4426950408889634f;
+  a.qblocks = (int)((d->T + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->dim_head) {
+    case 64: return launch_attn_dh<64>(a, d->B, d->causal, s);
+    case 128: return launch_attn_dh<128>(a, d->B, d->causal, s);
+    case 192: return launch_attn_dh<192>(a, d->B, d->causal, s);
+    default: return launch_attn_dh<384>(a, d->B, d->causal, s);
+  }
+}
+
 int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
                                    hipStream_t s) {
-  switch (dim_head) {
-    case 64: return launch_attn<64>(qkv, B, T, heads, scale, out, s);
-    case 128: return launch_attn<128>(qkv, B, T, heads, scale, out, s);
-    case 192: return launch_attn<192>(qkv, B, T, heads, scale, out, s);
-    case 384: return launch_attn<384>(qkv, B, T, heads, scale, out, s);
-    default: tribe_set_error("fused attention: unsupported dim_head %d", dim_head); return -1;
-  }
+  const int64_t inner = (int64_t)heads * dim_head;
+  tribe_attention_desc d;
+  d.q = qkv; d.k = qkv + inner; d.v = qkv + 2 * inner;
+  d.ld_q = d.ld_k = d.ld_v = 3 * inner;
+  d.out = out; d.ld_out = inner;
+  d.B = B; d.T = T; d.heads_q = heads; d.heads_kv = heads; d.dim_head = dim_head; d.causal = 0; d.scale = scale;
+  return tribe_attention_fwd_ex(&d, (void*)s);
 }

@@ -108,21 +108,19 @@ __global__ __launch_bounds__(256) void scalenorm_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------
 // partial rotary embedding, in place on the q and k sections of a fused qkv buffer
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rotary_kernel(unsigned short* __restrict__ qkv, int64_t rows, int64_t T, int heads,
-                                                     int dim_head, int rot_dim, const float* __restrict__ cos_tab,
+__global__ __launch_bounds__(256) void rotary_kernel(unsigned short* __restrict__ x, int64_t rows, int64_t T, int64_t row_stride,
+                                                     int n_heads, int dim_head, int rot_dim, const float* __restrict__ cos_tab,
                                                      const float* __restrict__ sin_tab, int interleaved) {
   const int half = rot_dim >> 1;
   const int items_per_head = half >> 2;  // each item rotates 4 pairs (8 elements)
-  const int64_t inner = (int64_t)heads * dim_head;
-  const int64_t total = rows * 2 * heads * items_per_head;
+  const int64_t total = rows * n_heads * items_per_head;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t t = idx;
     const int it = (int)(t % items_per_head); t /= items_per_head;
-    const int h = (int)(t % heads); t /= heads;
-    const int sec = (int)(t & 1);
-    const int64_t row = t >> 1;
+    const int h = (int)(t % n_heads);
+    const int64_t row = t / n_heads;
     const int64_t pos = row % T;
-    unsigned short* base = qkv + row * 3 * inner + sec * inner + (int64_t)h * dim_head;
+    unsigned short* base = x + row * row_stride + (int64_t)h * dim_head;
     const float4 c = *(const float4*)(cos_tab + pos * half + it * 4);
     const float4 s = *(const float4*)(sin_tab + pos * half + it * 4);
     const float cs[4] = {c.x, c.y, c.z, c.w}, sn[4] = {s.x, s.y, s.z, s.w};
@@ -147,6 +145,87 @@ __global__ __launch_bounds__(256) void rotary_kernel(unsigned short* __restrict_
       *(u16x4_t*)(base + half + it * 4) = hi;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// RMSNorm / LayerNorm: one wave per row (f32 in, f32 statistics), bf16 or f32 out
+// ---------------------------------------------------------------------------------
+template <int OUT_BF16, int LAYERNORM>
+__global__ __launch_bounds__(256) void rowstat_norm_kernel(const float* __restrict__ x, int64_t rows, int64_t dim,
+                                                           const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                           void* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = (const float4*)(x + row * dim);
+  const int64_t n4 = dim >> 2;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t i = lane; i < n4; i += 64) {
+    const float4 v = xr[i];
+    s1 += v.x + v.y + v.z + v.w;
+    s2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  float mean = 0.f, rstd;
+  if (LAYERNORM) {
+    mean = s1 / (float)dim;
+    float var = 0.f;  // second pass for the centred variance (row is L2-resident)
+    for (int64_t i = lane; i < n4; i += 64) {
+      const float4 v = xr[i];
+      const float a = v.x - mean, c = v.y - mean, d = v.z - mean, e = v.w - mean;
+      var += a * a + c * c + d * d + e * e;
+    }
+    var = wave_sum(var) / (float)dim;
+    rstd = rsqrtf(var + eps);
+  } else {
+    rstd = rsqrtf(s2 / (float)dim + eps);
+  }
+  for (int64_t i = lane; i < n4; i += 64) {
+    const float4 v = xr[i];
+    const float4 g = ((const float4*)w)[i];
+    float o0 = (v.x - mean) * rstd * g.x, o1 = (v.y - mean) * rstd * g.y, o2 = (v.z - mean) * rstd * g.z, o3 = (v.w - mean) * rstd * g.w;
+    if (LAYERNORM && b) {
+      const float4 bb = ((const float4*)b)[i];
+      o0 += bb.x; o1 += bb.y; o2 += bb.z; o3 += bb.w;
+    }
+    if (OUT_BF16) {
+      u16x4_t o;
+      o[0] = f32_to_bf16(o0); o[1] = f32_to_bf16(o1); o[2] = f32_to_bf16(o2); o[3] = f32_to_bf16(o3);
+      ((u16x4_t*)((unsigned short*)y + row * dim))[i] = o;
+    } else {
+      ((float4*)((float*)y + row * dim))[i] = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
+// embedding gather: one wave per token row
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_kernel(const T* __restrict__ table, const int64_t* __restrict__ ids, int64_t n,
+                                                        int64_t dim, int64_t vocab, float* __restrict__ x) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  int64_t id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // ids are validated on the host; clamp keeps a bad id from faulting
+  const T* src = table + id * dim;
+  for (int64_t i = lane; i < dim; i += 64) x[row * dim + i] = ld_as_f32<T>(src + i);
+}
+
+// segment mean over time: grid (dim/256, B)
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, int64_t T, int64_t dim,
+                                                           const int64_t* __restrict__ start, const int64_t* __restrict__ len,
+                                                           float* __restrict__ out, int64_t ld_out) {
+  const int64_t b = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dim) return;
+  int64_t s = start ? start[b] : 0, n = len ? len[b] : T;
+  if (s < 0) s = 0;
+  if (s + n > T) n = T - s;
+  float acc = 0.f;
+  const float* p = x + (b * T + s) * dim + c;
+  for (int64_t t = 0; t < n; ++t) acc += p[t * dim];
+  out[b * ld_out + c] = n > 0 ? acc / (float)n : 0.f;
 }
 
 // ---------------------------------------------------------------------------------
@@ -278,16 +357,73 @@ extern "C" int tribe_scalenorm_fwd(const float* x, int64_t rows, int64_t dim, co
   return 0;
 }
 
-extern "C" int tribe_rotary_fwd(uint16_t* qkv, int64_t rows, int64_t T, int32_t heads, int32_t dim_head, int32_t rot_dim,
-                                const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream) {
+extern "C" int tribe_rotary_fwd(uint16_t* x, int64_t rows, int64_t T, int64_t row_stride, int32_t n_heads, int32_t dim_head,
+                                int32_t rot_dim, const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream) {
   if (rot_dim == 0) return 0;
-  TRIBE_REQUIRE(qkv && cos_tab && sin_tab, "tribe_rotary_fwd: null pointer");
-  TRIBE_REQUIRE(rows > 0 && T > 0 && heads > 0 && dim_head > 0, "tribe_rotary_fwd: bad shape");
+  TRIBE_REQUIRE(x && cos_tab && sin_tab, "tribe_rotary_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && T > 0 && n_heads > 0 && dim_head > 0, "tribe_rotary_fwd: bad shape");
   TRIBE_REQUIRE(rot_dim > 0 && rot_dim <= dim_head && rot_dim % 8 == 0 && dim_head % 8 == 0,
                 "tribe_rotary_fwd: rot_dim=%d must be a multiple of 8 and <= dim_head=%d (dim_head %% 8 == 0)", rot_dim, dim_head);
-  const int64_t total = rows * 2 * heads * (rot_dim / 8);
-  hipLaunchKernelGGL(rotary_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, rows, T, heads,
+  TRIBE_REQUIRE(row_stride >= (int64_t)n_heads * dim_head && row_stride % 8 == 0, "tribe_rotary_fwd: bad row stride");
+  const int64_t total = rows * n_heads * (rot_dim / 8);
+  hipLaunchKernelGGL(rotary_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, T, row_stride, n_heads,
                      dim_head, rot_dim, cos_tab, sin_tab, interleaved);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_rmsnorm_fwd(const float* x, int64_t rows, int64_t dim, const float* w, float eps, void* y, int32_t y_dtype,
+                                 void* stream) {
+  TRIBE_REQUIRE(x && w && y, "tribe_rmsnorm_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0, "tribe_rmsnorm_fwd: rows=%lld dim=%lld (dim %% 4 required)", (long long)rows,
+                (long long)dim);
+  TRIBE_REQUIRE(y_dtype == TRIBE_F32 || y_dtype == TRIBE_BF16, "tribe_rmsnorm_fwd: y_dtype must be f32 or bf16");
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (y_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL((rowstat_norm_kernel<1, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, (const float*)nullptr, eps, y);
+  else
+    hipLaunchKernelGGL((rowstat_norm_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, (const float*)nullptr, eps, y);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_layernorm_fwd(const float* x, int64_t rows, int64_t dim, const float* w, const float* b, float eps, void* y,
+                                   int32_t y_dtype, void* stream) {
+  TRIBE_REQUIRE(x && w && y, "tribe_layernorm_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0, "tribe_layernorm_fwd: rows=%lld dim=%lld (dim %% 4 required)", (long long)rows,
+                (long long)dim);
+  TRIBE_REQUIRE(y_dtype == TRIBE_F32 || y_dtype == TRIBE_BF16, "tribe_layernorm_fwd: y_dtype must be f32 or bf16");
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (y_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL((rowstat_norm_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, b, eps, y);
+  else
+    hipLaunchKernelGGL((rowstat_norm_kernel<0, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, b, eps, y);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_embedding_fwd(const void* table, int32_t table_dtype, const int64_t* ids, int64_t n, int64_t dim, int64_t vocab,
+                                   float* x, void* stream) {
+  TRIBE_REQUIRE(table && ids && x, "tribe_embedding_fwd: null pointer");
+  TRIBE_REQUIRE(n > 0 && dim > 0 && vocab > 0, "tribe_embedding_fwd: bad shape");
+  dim3 grid((unsigned)((n + 3) / 4));
+  if (table_dtype == TRIBE_F32)
+    hipLaunchKernelGGL(embedding_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)table, ids, n, dim, vocab, x);
+  else if (table_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL(embedding_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)table, ids, n,
+                       dim, vocab, x);
+  else
+    TRIBE_REQUIRE(false, "tribe_embedding_fwd: table dtype must be f32 or bf16");
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_segment_mean_fwd(const float* x, int64_t B, int64_t T, int64_t dim, const int64_t* start, const int64_t* len,
+                                      float* out, int64_t ld_out, void* stream) {
+  TRIBE_REQUIRE(x && out, "tribe_segment_mean_fwd: null pointer");
+  TRIBE_REQUIRE(B > 0 && T > 0 && dim > 0 && ld_out >= dim && B < 65536, "tribe_segment_mean_fwd: bad shape");
+  dim3 grid((unsigned)((dim + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(segment_mean_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, T, dim, start, len, out, ld_out);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

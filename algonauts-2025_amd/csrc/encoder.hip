@@ -197,7 +197,9 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.role = TRIBE_ROLE_QKV;
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
-    rc = tribe_rotary_fwd(qkv, M, d->T, d->heads, d->dim_head, d->rot_dim, d->cos_tab, d->sin_tab, d->rotary_interleaved, stream);
+    // q heads and k heads are adjacent in the fused row: rotate the first 2*heads heads
+    rc = tribe_rotary_fwd(qkv, M, d->T, 3 * inner, 2 * d->heads, d->dim_head, d->rot_dim, d->cos_tab, d->sin_tab,
+                          d->rotary_interleaved, stream);
     if (rc) return rc;
     rc = tribe_attention_fwd(qkv, d->B, d->T, d->heads, d->dim_head, scale, ao, attn_ws, p.attn_bytes, stream);
     if (rc) return rc;

@@ -1,0 +1,131 @@
+// Frozen feature extractors as sequences of the path's own kernels:
+// host-side orchestration only (no allocation, no sync), one C entry point per architecture.
+//
+// tribe_llama_fwd: transformers LlamaModel forward with output_hidden_states=True
+// (data_utils/features/text.py:236-240 -> modeling_llama.py LlamaDecoderLayer: RMSNorm -> GQA attention with
+// rotary (rotate_half) and a causal mask -> residual -> RMSNorm -> SwiGLU MLP -> residual), fused with the
+// reference's per-word pooling of every hidden state (text.py:245-254: strip right padding, mean of the last
+// len(word) positions) so that only [n_states, B, dim] floats leave the GPU instead of every hidden state.
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+inline tribe_gemm_desc gemm_zero() {
+  tribe_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.batch1 = d.batch0 = 1;
+  d.alpha = 1.0f;
+  d.c_dtype = TRIBE_F32;
+  return d;
+}
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct LlamaPlan {
+  int64_t M, qkv_w, q_w;
+  size_t x_b, xn_b, qkv_b, ao_b, act_b, fin_b;
+};
+inline LlamaPlan llama_plan(const tribe_llama_desc* d) {
+  LlamaPlan p;
+  p.M = d->B * d->T;
+  p.q_w = (int64_t)d->heads_q * d->dim_head;
+  p.qkv_w = (int64_t)(d->heads_q + 2 * d->heads_kv) * d->dim_head;
+  p.x_b = align256((size_t)p.M * d->dim * 4);
+  p.xn_b = align256((size_t)p.M * d->dim * 2);
+  p.qkv_b = align256((size_t)p.M * p.qkv_w * 2);
+  p.ao_b = align256((size_t)p.M * p.q_w * 2);
+  p.act_b = align256((size_t)p.M * d->inter * 2);
+  p.fin_b = align256((size_t)p.M * d->dim * 4);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t tribe_llama_workspace_bytes(const tribe_llama_desc* d) {
+  if (!d || d->B <= 0 || d->T <= 0) return 0;
+  const LlamaPlan p = llama_plan(d);
+  return p.x_b + p.xn_b + p.qkv_b + p.ao_b + p.act_b + p.fin_b;
+}
+
+extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream) {
+  TRIBE_REQUIRE(d && states && workspace, "tribe_llama_fwd: null pointer");
+  TRIBE_REQUIRE(d->B > 0 && d->T > 0 && d->dim > 0 && d->depth >= 0 && d->heads_q > 0 && d->heads_kv > 0 && d->inter > 0,
+                "tribe_llama_fwd: bad shape");
+  TRIBE_REQUIRE(d->heads_q % d->heads_kv == 0, "tribe_llama_fwd: heads_q=%d not a multiple of heads_kv=%d", d->heads_q, d->heads_kv);
+  TRIBE_REQUIRE(d->dim % 64 == 0 && d->inter % 64 == 0 && (d->heads_q * d->dim_head) % 64 == 0,
+                "tribe_llama_fwd: dim, inter and heads_q*dim_head must be multiples of 64");
+  TRIBE_REQUIRE(d->embed && d->ids && d->final_norm_w && d->cos_tab && d->sin_tab && (d->depth == 0 || d->layers_host),
+                "tribe_llama_fwd: missing parameter pointer");
+  TRIBE_REQUIRE(((uintptr_t)workspace % 256) == 0, "tribe_llama_fwd: workspace must be 256-byte aligned");
+  TRIBE_REQUIRE(workspace_bytes >= tribe_llama_workspace_bytes(d), "tribe_llama_fwd: workspace too small");
+  const LlamaPlan p = llama_plan(d);
+  char* w = (char*)workspace;
+  float* x = (float*)w; w += p.x_b;
+  uint16_t* xn = (uint16_t*)w; w += p.xn_b;
+  uint16_t* qkv = (uint16_t*)w; w += p.qkv_b;
+  uint16_t* ao = (uint16_t*)w; w += p.ao_b;
+  uint16_t* act = (uint16_t*)w; w += p.act_b;
+  float* fin = (float*)w;
+  const int64_t M = p.M, dim = d->dim, BD = d->B * dim;
+
+  int rc = tribe_embedding_fwd(d->embed, d->embed_dtype, d->ids, M, dim, d->vocab, x, stream);
+  if (rc) return rc;
+  rc = tribe_segment_mean_fwd(x, d->B, d->T, dim, d->pool_start, d->pool_len, states, dim, stream);
+  if (rc) return rc;
+
+  for (int l = 0; l < d->depth; ++l) {
+    const tribe_llama_layer& L = d->layers_host[l];
+    TRIBE_REQUIRE(L.input_norm_w && L.w_qkv && L.w_o && L.post_norm_w && L.w_gate_up && L.w_down,
+                  "tribe_llama_fwd: layer %d has a null parameter", l);
+    rc = tribe_rmsnorm_fwd(x, M, dim, L.input_norm_w, d->rms_eps, xn, TRIBE_BF16, stream);
+    if (rc) return rc;
+    tribe_gemm_desc g = gemm_zero();
+    g.M = M; g.N = p.qkv_w; g.K = dim;
+    g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
+    g.C = qkv; g.ldc = p.qkv_w; g.c_dtype = TRIBE_BF16; g.role = TRIBE_ROLE_QKV;
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    // rotate_half rotary over the full head dim on the q heads and the k heads (adjacent in the fused row)
+    rc = tribe_rotary_fwd(qkv, M, d->T, p.qkv_w, d->heads_q + d->heads_kv, d->dim_head, d->dim_head, d->cos_tab, d->sin_tab, 0, stream);
+    if (rc) return rc;
+    tribe_attention_desc a;
+    a.q = qkv; a.k = qkv + p.q_w; a.v = qkv + p.q_w + (int64_t)d->heads_kv * d->dim_head;
+    a.ld_q = a.ld_k = a.ld_v = p.qkv_w;
+    a.out = ao; a.ld_out = p.q_w;
+    a.B = d->B; a.T = d->T; a.heads_q = d->heads_q; a.heads_kv = d->heads_kv; a.dim_head = d->dim_head;
+    a.causal = 1;  // right padding + causal mask: real tokens never see pad keys, pad rows are never pooled
+    a.scale = 1.0f / sqrtf((float)d->dim_head);
+    rc = tribe_attention_fwd_ex(&a, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = dim; g.K = p.q_w;
+    g.A = ao; g.lda = p.q_w; g.B = L.w_o; g.ldb = p.q_w;
+    g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_OUT_PROJ;
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    rc = tribe_rmsnorm_fwd(x, M, dim, L.post_norm_w, d->rms_eps, xn, TRIBE_BF16, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = 2 * (int64_t)d->inter; g.K = dim;
+    g.A = xn; g.lda = dim; g.B = L.w_gate_up; g.ldb = dim;
+    g.C = act; g.ldc = d->inter; g.c_dtype = TRIBE_BF16; g.act = TRIBE_ACT_SWIGLU; g.role = TRIBE_ROLE_FF1;
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = dim; g.K = d->inter;
+    g.A = act; g.lda = d->inter; g.B = L.w_down; g.ldb = d->inter;
+    g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_FF2;
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    if (l + 1 < d->depth) {
+      rc = tribe_segment_mean_fwd(x, d->B, d->T, dim, d->pool_start, d->pool_len, states + (int64_t)(l + 1) * BD, dim, stream);
+      if (rc) return rc;
+    }
+  }
+  // the last hidden state is the output of the final RMSNorm (LlamaModel.norm)
+  if (d->depth > 0) {
+    rc = tribe_rmsnorm_fwd(x, M, dim, d->final_norm_w, d->rms_eps, fin, TRIBE_F32, stream);
+    if (rc) return rc;
+    rc = tribe_segment_mean_fwd(fin, d->B, d->T, dim, d->pool_start, d->pool_len, states + (int64_t)d->depth * BD, dim, stream);
+  }
+  return rc;
+}

@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libtribe_hip.so"
 
 F32, BF16, F64 = 0, 1, 2
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU = 0, 1, 2, 3
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head"]
 
@@ -40,6 +40,36 @@ class GemmDesc(C.Structure):
         ("rowadd", vp), ("ld_rowadd", i64), ("rowadd_period", i64),
         ("gadd", vp), ("gadd_index", vp), ("gadd_div", i64), ("ld_gadd", i64),
         ("role", i32), ("tile_hint", i32),
+    ]
+
+
+class AttentionDesc(C.Structure):
+    """struct tribe_attention_desc"""
+
+    _fields_ = [
+        ("q", vp), ("k", vp), ("v", vp), ("ld_q", i64), ("ld_k", i64), ("ld_v", i64),
+        ("out", vp), ("ld_out", i64), ("B", i64), ("T", i64),
+        ("heads_q", i32), ("heads_kv", i32), ("dim_head", i32), ("causal", i32), ("scale", f32),
+    ]
+
+
+class LlamaLayer(C.Structure):
+    """struct tribe_llama_layer"""
+
+    _fields_ = [("input_norm_w", vp), ("w_qkv", vp), ("w_o", vp), ("post_norm_w", vp), ("w_gate_up", vp), ("w_down", vp)]
+
+
+class LlamaDesc(C.Structure):
+    """struct tribe_llama_desc"""
+
+    _fields_ = [
+        ("B", i64), ("T", i64),
+        ("dim", i32), ("depth", i32), ("heads_q", i32), ("heads_kv", i32), ("dim_head", i32), ("inter", i32),
+        ("rms_eps", f32),
+        ("embed", vp), ("embed_dtype", i32), ("vocab", i64),
+        ("layers_host", C.POINTER(LlamaLayer)),
+        ("final_norm_w", vp), ("cos_tab", vp), ("sin_tab", vp),
+        ("ids", vp), ("pool_start", vp), ("pool_len", vp),
     ]
 
 
@@ -79,7 +109,14 @@ SIGNATURES = {
     "tribe_projector_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, i64, vp, i64, i64, i32, vp, vp, vp, vp]),
     "tribe_projector_zero_fwd": (C.c_int, [i64, i64, i64, vp, i64, i64, vp, vp, vp, vp]),
     "tribe_scalenorm_fwd": (C.c_int, [vp, i64, i64, vp, f32, f32, vp, i32, vp]),
-    "tribe_rotary_fwd": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, vp, i32, vp]),
+    "tribe_rotary_fwd": (C.c_int, [vp, i64, i64, i64, i32, i32, i32, vp, vp, i32, vp]),
+    "tribe_attention_fwd_ex": (C.c_int, [C.POINTER(AttentionDesc), vp]),
+    "tribe_embedding_fwd": (C.c_int, [vp, i32, vp, i64, i64, i64, vp, vp]),
+    "tribe_rmsnorm_fwd": (C.c_int, [vp, i64, i64, vp, f32, vp, i32, vp]),
+    "tribe_layernorm_fwd": (C.c_int, [vp, i64, i64, vp, vp, f32, vp, i32, vp]),
+    "tribe_segment_mean_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
+    "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
+    "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),
     "tribe_attention_set_mode": (C.c_int, [i32]),
     "tribe_attention_fwd": (C.c_int, [vp, i64, i64, i32, i32, f32, vp, vp, sz, vp]),

@@ -10,7 +10,7 @@ import typing as tp
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, F64, EncoderDesc, EncoderLayer, GemmDesc, check, lib
+from ._lib import BF16, F32, F64, AttentionDesc, EncoderDesc, EncoderLayer, GemmDesc, LlamaDesc, LlamaLayer, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float64: F64}
 
@@ -77,21 +77,22 @@ def gemm_nt(
         raise ValueError(f"gemm_nt: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
     Z, M, K = a3.shape
     N = b3.shape[1]
+    n_out = N // 2 if act == "swiglu" else N  # SwiGLU folds (gate, up) column pairs
     if out is None:
-        out = torch.empty((Z, M, N) if a.ndim == 3 else (M, N), dtype=out_dtype, device=a.device)
+        out = torch.empty((Z, M, n_out) if a.ndim == 3 else (M, n_out), dtype=out_dtype, device=a.device)
     _cuda(out, (torch.float32, torch.bfloat16), "out")
     d = GemmDesc()
     d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, Z, 1
     d.A, d.lda, d.sA1 = a3.data_ptr(), K, M * K
     d.B, d.ldb, d.sB1 = b3.data_ptr(), K, N * K
-    d.C, d.ldc, d.sC1 = out.data_ptr(), N, M * N
+    d.C, d.ldc, d.sC1 = out.data_ptr(), n_out, M * n_out
     d.c_dtype = _DT[out.dtype]
     d.alpha = alpha
     d.tile_hint = tile_hint
     if bias is not None:
         _cuda(bias, torch.float32, "bias")
         d.bias, d.bias_mode = bias.data_ptr(), (_lib.BIAS_ROW if bias_row else _lib.BIAS_COL)
-    d.act = _lib.ACT_GELU if act == "gelu" else _lib.ACT_NONE
+    d.act = {"gelu": _lib.ACT_GELU, "swiglu": _lib.ACT_SWIGLU, "silu": _lib.ACT_SILU, None: _lib.ACT_NONE}[act]
     if res is not None:
         _cuda(res, torch.float32, "res")
         d.res, d.ldres, d.sRes1 = res.data_ptr(), N, M * N
@@ -188,14 +189,75 @@ def scalenorm(x: torch.Tensor, g: torch.Tensor, gain_scale: float, eps: float, o
 
 
 def rotary_(qkv: torch.Tensor, T: int, heads: int, dim_head: int, rot_dim: int, cos: torch.Tensor, sin: torch.Tensor,
-            interleaved: bool) -> torch.Tensor:
+            interleaved: bool, heads_kv: int | None = None) -> torch.Tensor:
+    """In-place rotary on the q heads and k heads of a fused [rows, (heads + 2*heads_kv) * dim_head] buffer."""
     _cuda(qkv, torch.bfloat16, "qkv")
-    rows = qkv.numel() // (3 * heads * dim_head)
+    heads_kv = heads if heads_kv is None else heads_kv
+    row_stride = (heads + 2 * heads_kv) * dim_head
+    rows = qkv.numel() // row_stride
     if cos.shape != (T, rot_dim // 2) or sin.shape != cos.shape:
         raise ValueError(f"rotary_: tables must be [T, rot_dim/2] = {(T, rot_dim // 2)}, got {tuple(cos.shape)}")
-    check(lib().tribe_rotary_fwd(qkv.data_ptr(), rows, T, heads, dim_head, rot_dim, _cuda(cos, torch.float32, "cos").data_ptr(),
-                                 _cuda(sin, torch.float32, "sin").data_ptr(), int(interleaved), _stream()), "tribe_rotary_fwd")
+    check(lib().tribe_rotary_fwd(qkv.data_ptr(), rows, T, row_stride, heads + heads_kv, dim_head, rot_dim,
+                                 _cuda(cos, torch.float32, "cos").data_ptr(), _cuda(sin, torch.float32, "sin").data_ptr(),
+                                 int(interleaved), _stream()), "tribe_rotary_fwd")
     return qkv
+
+
+def attention_gqa(qkv: torch.Tensor, B: int, T: int, heads_q: int, heads_kv: int, dim_head: int, scale: float,
+                  causal: bool) -> torch.Tensor:
+    """Fused attention on a [B*T, (heads_q + 2*heads_kv) * dim_head] q|k|v buffer (grouped-query, optional causal mask)."""
+    _cuda(qkv, torch.bfloat16, "qkv")
+    width = (heads_q + 2 * heads_kv) * dim_head
+    if qkv.numel() != B * T * width:
+        raise ValueError("attention_gqa: qkv has the wrong number of elements")
+    out = torch.empty(B * T, heads_q * dim_head, dtype=torch.bfloat16, device=qkv.device)
+    d = AttentionDesc()
+    base = qkv.data_ptr()
+    d.q, d.k, d.v = base, base + 2 * heads_q * dim_head, base + 2 * (heads_q + heads_kv) * dim_head
+    d.ld_q = d.ld_k = d.ld_v = width
+    d.out, d.ld_out = out.data_ptr(), heads_q * dim_head
+    d.B, d.T, d.heads_q, d.heads_kv, d.dim_head, d.causal, d.scale = B, T, heads_q, heads_kv, dim_head, int(causal), scale
+    check(lib().tribe_attention_fwd_ex(C.byref(d), _stream()), "tribe_attention_fwd_ex")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    _cuda(x, torch.float32, "x")
+    _cuda(w, torch.float32, "w")
+    dim = x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib().tribe_rmsnorm_fwd(x.data_ptr(), x.numel() // dim, dim, w.data_ptr(), eps, y.data_ptr(), _DT[out_dtype], _stream()),
+          "tribe_rmsnorm_fwd")
+    return y
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, eps: float, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    _cuda(x, torch.float32, "x")
+    _cuda(w, torch.float32, "w")
+    dim = x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib().tribe_layernorm_fwd(x.data_ptr(), x.numel() // dim, dim, w.data_ptr(), _p(b), eps, y.data_ptr(), _DT[out_dtype],
+                                    _stream()), "tribe_layernorm_fwd")
+    return y
+
+
+def embedding(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    _cuda(table, (torch.float32, torch.bfloat16), "table")
+    _cuda(ids, torch.int64, "ids")
+    vocab, dim = table.shape
+    x = torch.empty(ids.numel(), dim, dtype=torch.float32, device=table.device)
+    check(lib().tribe_embedding_fwd(table.data_ptr(), _DT[table.dtype], ids.data_ptr(), ids.numel(), dim, vocab, x.data_ptr(), _stream()),
+          "tribe_embedding_fwd")
+    return x
+
+
+def segment_mean(x: torch.Tensor, B: int, T: int, start: torch.Tensor | None, length: torch.Tensor | None) -> torch.Tensor:
+    _cuda(x, torch.float32, "x")
+    dim = x.shape[-1]
+    out = torch.empty(B, dim, dtype=torch.float32, device=x.device)
+    check(lib().tribe_segment_mean_fwd(x.data_ptr(), B, T, dim, _p(start), _p(length), out.data_ptr(), dim, _stream()),
+          "tribe_segment_mean_fwd")
+    return out
 
 
 def attention_set_mode(mode: int) -> None:

@@ -33,7 +33,12 @@ extern "C" {
 #define TRIBE_ABI_VERSION 1
 
 enum tribe_dtype { TRIBE_F32 = 0, TRIBE_BF16 = 1, TRIBE_F64 = 2 };
-enum tribe_act { TRIBE_ACT_NONE = 0, TRIBE_ACT_GELU = 1 };
+enum tribe_act {
+  TRIBE_ACT_NONE = 0,
+  TRIBE_ACT_GELU = 1,   /* exact (erf) GELU */
+  TRIBE_ACT_SWIGLU = 2, /* columns come in (gate, up) pairs: out[:, j] = silu(v[:, 2j]) * v[:, 2j+1]; C has N/2 columns */
+  TRIBE_ACT_SILU = 3
+};
 enum tribe_bias_mode { TRIBE_BIAS_NONE = 0, TRIBE_BIAS_COL = 1, TRIBE_BIAS_ROW = 2 };
 /* which operator of the path a GEMM launch serves: selects the kernel SYMBOL (per-operator rows in
  * rocprofv3 --stats and in the tribe_prof_* event profile); arithmetic is identical for all roles */
@@ -122,10 +127,12 @@ int tribe_projector_zero_fwd(int64_t BT, int64_t T, int64_t N_out, float* x, int
 /* ScaleNorm: y = x / max(||x||_2, eps) * gain_scale * g[0]  (g read on device) */
 int tribe_scalenorm_fwd(const float* x, int64_t rows, int64_t dim, const float* g, float gain_scale, float eps,
                         void* y, int32_t y_dtype, void* stream);
-/* partial rotary on q and k inside a fused qkv buffer [rows, 3*heads*dim_head] bf16, in place.
- * cos/sin: f32 [T, rot_dim/2]; interleaved != 0 pairs (2i,2i+1), else (i, i+rot_dim/2). */
-int tribe_rotary_fwd(uint16_t* qkv, int64_t rows, int64_t T, int32_t heads, int32_t dim_head, int32_t rot_dim,
-                     const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream);
+/* (partial) rotary embedding, in place, on the first n_heads heads of every row of a bf16 buffer with row stride
+ * row_stride elements (a fused qkv buffer: q heads followed by k heads).  Position of row r is r % T.
+ * cos/sin: f32 [T, rot_dim/2]; interleaved != 0 pairs (2i,2i+1) (x_transformers 2.x), else (i, i+rot_dim/2)
+ * (x_transformers 1.27 and HF rotate_half, modeling_llama.py). */
+int tribe_rotary_fwd(uint16_t* x, int64_t rows, int64_t T, int64_t row_stride, int32_t n_heads, int32_t dim_head,
+                     int32_t rot_dim, const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream);
 /* softmax(q k^T * scale) v for all (batch, head); qkv as above; out bf16 [rows, heads*dim_head] */
 size_t tribe_attention_workspace_bytes(int64_t B, int64_t T, int32_t heads, int32_t dim_head);
 /* 0 (default): fused flash-style kernel for dim_head in {64,128,192,384}, else the materialised path;
@@ -133,6 +140,18 @@ size_t tribe_attention_workspace_bytes(int64_t B, int64_t T, int32_t heads, int3
 int tribe_attention_set_mode(int32_t mode);
 int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, int32_t heads, int32_t dim_head, float scale,
                         uint16_t* out, void* workspace, size_t workspace_bytes, void* stream);
+/* general form of the fused kernel: separate q / k / v views (row = b*T + t, row strides in elements, ld_k == ld_v),
+ * grouped-query attention (heads_q % heads_kv == 0; query head h reads kv head h / (heads_q/heads_kv)) and an
+ * optional causal mask (key <= query).  dim_head in {64, 128, 192, 384}.  out[row][h*dim_head + d]. */
+typedef struct tribe_attention_desc {
+  const uint16_t* q; const uint16_t* k; const uint16_t* v;
+  int64_t ld_q, ld_k, ld_v;
+  uint16_t* out; int64_t ld_out;
+  int64_t B, T;
+  int32_t heads_q, heads_kv, dim_head, causal;
+  float scale;
+} tribe_attention_desc;
+int tribe_attention_fwd_ex(const tribe_attention_desc* desc, void* stream);
 
 typedef struct tribe_encoder_layer {
   /* attention block */
@@ -162,6 +181,49 @@ size_t tribe_encoder_workspace_bytes(const tribe_encoder_desc* d);
 /* x: f32 [B*T, dim] residual stream, updated in place; y: final-normed output (bf16 or f32) [B*T, dim] */
 int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y, int32_t y_dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a16-a18: building blocks of the frozen extractors (HF transformers architectures)
+ * ------------------------------------------------------------------------- */
+/* x[i, :] = table[ids[i], :]  (nn.Embedding; table f32 or bf16 -> x f32) */
+int tribe_embedding_fwd(const void* table, int32_t table_dtype, const int64_t* ids, int64_t n, int64_t dim, int64_t vocab,
+                        float* x, void* stream);
+/* LlamaRMSNorm (modeling_llama.py:51-66): y = x * rsqrt(mean(x^2) + eps) * w */
+int tribe_rmsnorm_fwd(const float* x, int64_t rows, int64_t dim, const float* w, float eps, void* y, int32_t y_dtype,
+                      void* stream);
+/* nn.LayerNorm over the last axis: y = (x - mean) * rsqrt(var + eps) * w + b */
+int tribe_layernorm_fwd(const float* x, int64_t rows, int64_t dim, const float* w, const float* b, float eps, void* y,
+                        int32_t y_dtype, void* stream);
+/* out[b, :] = mean_{t in [start[b], start[b]+len[b])} x[b*T + t, :]   (text.py:245-254: mean of the last len(word)
+ * non-pad positions; video.py:228: mean over all tokens).  x f32 [B*T, dim] -> out f32, row stride ld_out. */
+int tribe_segment_mean_fwd(const float* x, int64_t B, int64_t T, int64_t dim, const int64_t* start, const int64_t* len,
+                           float* out, int64_t ld_out, void* stream);
+
+typedef struct tribe_llama_layer {
+  const float* input_norm_w;     /* [dim] */
+  const uint16_t* w_qkv;         /* bf16 [(hq + 2 hkv) * dh, dim]: q | k | v rows */
+  const uint16_t* w_o;           /* bf16 [dim, hq * dh] */
+  const float* post_norm_w;      /* [dim] */
+  const uint16_t* w_gate_up;     /* bf16 [2 * inter, dim], rows interleaved: gate_0, up_0, gate_1, up_1, ... */
+  const uint16_t* w_down;        /* bf16 [dim, inter] */
+} tribe_llama_layer;
+
+typedef struct tribe_llama_desc {
+  int64_t B, T;                  /* right-padded batch of token ids */
+  int32_t dim, depth, heads_q, heads_kv, dim_head, inter;
+  float rms_eps;
+  const void* embed; int32_t embed_dtype; int64_t vocab;
+  const tribe_llama_layer* layers_host;   /* HOST array [depth] */
+  const float* final_norm_w;
+  const float* cos_tab; const float* sin_tab;   /* f32 [T, dim_head/2] (rope scaling already applied) */
+  const int64_t* ids;            /* [B*T] */
+  const int64_t* pool_start; const int64_t* pool_len;  /* [B] token window averaged per hidden state */
+} tribe_llama_desc;
+
+size_t tribe_llama_workspace_bytes(const tribe_llama_desc* d);
+/* LlamaModel forward with output_hidden_states (text.py:236-240) fused with the per-word pooling of
+ * text.py:245-254: states f32 [depth + 1, B, dim] (state 0 = embeddings, last = after the final RMSNorm). */
+int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * a7 + a8: SubjectLayers.forward (common.py:45-67) and AdaptiveAvgPool1d (model.py:119-120)

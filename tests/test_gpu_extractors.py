@@ -1,0 +1,118 @@
+"""GPU parity of the frozen-extractor forwards against the installed `transformers` implementation (the classes the
+reference instantiates), random weights from a local config -- real checkpoints are remote-only (parity unpinned for
+them).  Tolerances: bf16 GEMM operands with f32 accumulation and f32 residual stream vs an fp32 CPU model."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import extractors_ref  # noqa: E402
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+def test_extractor_building_blocks():
+    from tribe_hip import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 512, generator=g) * 2
+    w, b = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g)
+    want = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * w  # modeling_llama.py:61-66
+    torch.testing.assert_close(ops.rmsnorm(x.cuda(), w.cuda(), 1e-5, torch.float32).cpu(), want, rtol=1e-5, atol=1e-5)
+    want = torch.nn.functional.layer_norm(x, (512,), w, b, 1e-6)
+    torch.testing.assert_close(ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6, torch.float32).cpu(), want, rtol=1e-4, atol=1e-5)
+    table = torch.randn(50, 64, generator=g)
+    ids = torch.randint(0, 50, (3, 5), generator=g)
+    torch.testing.assert_close(ops.embedding(table.cuda(), ids.cuda()).cpu(), table[ids.flatten()], rtol=0, atol=0)
+    seq = torch.randn(3 * 7, 64, generator=g)
+    start, length = torch.tensor([0, 2, 5]), torch.tensor([7, 3, 2])
+    got = ops.segment_mean(seq.cuda(), 3, 7, start.cuda(), length.cuda()).cpu()
+    want = torch.stack([seq.view(3, 7, 64)[i, s:s + n].mean(0) for i, (s, n) in enumerate(zip(start.tolist(), length.tolist()))])
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    # SwiGLU epilogue: out[:, j] = silu(v[:, 2j]) * v[:, 2j+1]
+    a, wgu = bf(torch.randn(70, 128, generator=g)), bf(torch.randn(2 * 96, 128, generator=g) / 11)
+    v = a @ wgu.t()
+    want = torch.nn.functional.silu(v[:, 0::2]) * v[:, 1::2]
+    got = ops.gemm_nt(a.cuda().bfloat16(), wgu.cuda().bfloat16(), act="swiglu", out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,hq,hkv,d,causal", [(2, 70, 4, 2, 64, True), (1, 300, 6, 2, 128, True), (2, 129, 3, 1, 128, False),
+                                                   (1, 1024, 24, 8, 128, True)])
+def test_attention_gqa_causal(B, T, hq, hkv, d, causal):
+    from tribe_hip import ops
+
+    g = torch.Generator().manual_seed(1)
+    width = (hq + 2 * hkv) * d
+    qkv = bf(torch.randn(B * T, width, generator=g))
+    out = ops.attention_gqa(qkv.cuda().bfloat16(), B, T, hq, hkv, d, d**-0.5, causal).float().cpu()
+    q = qkv[:, : hq * d].view(B, T, hq, d).transpose(1, 2)
+    k = qkv[:, hq * d:(hq + hkv) * d].view(B, T, hkv, d).transpose(1, 2).repeat_interleave(hq // hkv, dim=1)  # repeat_kv
+    v = qkv[:, (hq + hkv) * d:].view(B, T, hkv, d).transpose(1, 2).repeat_interleave(hq // hkv, dim=1)
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * d**-0.5
+    if causal:
+        sim = sim.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1), float("-inf"))
+    want = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).transpose(1, 2).reshape(B * T, hq * d)
+    torch.testing.assert_close(out, want, rtol=2**-6, atol=4e-3)
+
+
+def _tiny_llama(layers=3, hidden=256, heads=4, kv=2, head_dim=64, inter=512, vocab=300):
+    from transformers import LlamaConfig, LlamaModel
+
+    cfg = LlamaConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                      num_attention_heads=heads, num_key_value_heads=kv, head_dim=head_dim, max_position_embeddings=16384,
+                      rms_norm_eps=1e-5, tie_word_embeddings=True,
+                      rope_parameters={"rope_type": "llama3", "rope_theta": 500000.0, "factor": 32.0, "low_freq_factor": 1.0,
+                                       "high_freq_factor": 4.0, "original_max_position_embeddings": 8192})
+    torch.manual_seed(0)
+    return cfg, LlamaModel(cfg).eval()
+
+
+def test_rope_inv_freq_matches_hf():
+    from data_utils.features.text import rope_inv_freq
+
+    cfg, hf = _tiny_llama()
+    torch.testing.assert_close(rope_inv_freq(64, dict(cfg.rope_parameters)), hf.rotary_emb.inv_freq.float().cpu(), rtol=1e-6, atol=0)
+    torch.testing.assert_close(rope_inv_freq(128, {"rope_type": "default", "rope_theta": 10000.0}),
+                               1.0 / (10000.0 ** (torch.arange(0, 128, 2).float() / 128)))
+
+
+@pytest.mark.parametrize("shape", ["tiny", "wide"])
+def test_llama_word_states_vs_transformers(shape):
+    """text.py:204-256 semantics end to end: HF LlamaModel (fp32, CPU) + the reference's pad-strip / last-len(word) mean
+    vs tribe_llama_fwd.  'wide' uses the real Llama-3.2-3B widths (3072, 24/8 heads x 128, MLP 8192) on 2 layers."""
+    from data_utils.features.text import HipLlamaModel, word_pool_windows
+
+    if shape == "tiny":
+        cfg, hf = _tiny_llama()
+    else:
+        cfg, hf = _tiny_llama(layers=2, hidden=3072, heads=24, kv=8, head_dim=128, inter=8192, vocab=512)
+    pad_id = 7
+    g = torch.Generator().manual_seed(3)
+    B, T = 4, 45
+    ids = torch.randint(8, cfg.vocab_size, (B, T), generator=g)
+    n_real = [45, 30, 12, 3]
+    mask = torch.ones(B, T, dtype=torch.long)
+    for i, n in enumerate(n_real):
+        ids[i, n:] = pad_id  # right padding with the eos/pad id (text.py:182-183)
+        mask[i, n:] = 0
+    words = ["hello", "a", "extraordinarily", "toolongword"]  # the last window is longer than its 3-token context
+    want = extractors_ref.llama_word_states(hf, ids, mask, words, pad_id)
+    model = HipLlamaModel(cfg, hf.state_dict())
+    start, length = word_pool_windows(ids, words, pad_id)
+    got = model.forward_pooled(ids, start, length).cpu().numpy()  # [n_states, B, dim]
+    assert got.shape == (cfg.num_hidden_layers + 1, B, cfg.hidden_size)
+    for j in range(B):
+        assert want[j].shape == got[:, j].shape
+        np.testing.assert_allclose(got[0, j], want[j][0], rtol=0, atol=4e-3 * np.abs(want[j][0]).max() + 1e-6)  # bf16 embedding table
+        err = _rel(got[:, j], want[j])
+        assert err < 1.5e-2, f"word {j}: relative L2 error {err:.2e}"
