@@ -121,6 +121,22 @@ __global__ __launch_bounds__(256) void rotary_kernel(unsigned short* __restrict_
     const int64_t row = t / n_heads;
     const int64_t pos = row % T;
     unsigned short* base = x + row * row_stride + (int64_t)h * dim_head;
+    if (interleaved == 2) {
+      // per-ELEMENT tables [T, rot_dim] with interleaved pairs: out[2p] = a C[2p] - b S[2p], out[2p+1] = b C[2p+1] + a S[2p+1]
+      // (VJEPA2 rotate_queries_or_keys tiles its frequencies, so the two elements of a pair see different angles)
+      const float4 c0 = *(const float4*)(cos_tab + pos * rot_dim + it * 8), c1 = *(const float4*)(cos_tab + pos * rot_dim + it * 8 + 4);
+      const float4 s0 = *(const float4*)(sin_tab + pos * rot_dim + it * 8), s1 = *(const float4*)(sin_tab + pos * rot_dim + it * 8 + 4);
+      const float ce[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, se[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      u16x8_t v = *(u16x8_t*)(base + it * 8);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float a = bf16_to_f32(v[2 * p]), b = bf16_to_f32(v[2 * p + 1]);
+        v[2 * p] = f32_to_bf16(a * ce[2 * p] - b * se[2 * p]);
+        v[2 * p + 1] = f32_to_bf16(b * ce[2 * p + 1] + a * se[2 * p + 1]);
+      }
+      *(u16x8_t*)(base + it * 8) = v;
+      continue;
+    }
     const float4 c = *(const float4*)(cos_tab + pos * half + it * 4);
     const float4 s = *(const float4*)(sin_tab + pos * half + it * 4);
     const float cs[4] = {c.x, c.y, c.z, c.w}, sn[4] = {s.x, s.y, s.z, s.w};
@@ -196,6 +212,41 @@ __global__ __launch_bounds__(256) void rowstat_norm_kernel(const float* __restri
     } else {
       ((float4*)((float*)y + row * dim))[i] = make_float4(o0, o1, o2, o3);
     }
+  }
+}
+
+// Conv3d(stride == kernel) patch embedding as a GEMM: unfold pixels [B, F, C, H, W] into rows of
+// K = C * tub * p * p (k = ((c * tub + dt) * p + dy) * p + dx, the Conv3d weight's own flattening), 8 outputs per thread
+__global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__ pix, int64_t B, int F, int Cc, int H, int W, int tub,
+                                                       int p, unsigned short* __restrict__ out, int64_t K_pad) {
+  const int gh = H / p, gw = W / p, gf = F / tub;
+  const int64_t tokens = (int64_t)gf * gh * gw;
+  const int64_t K = (int64_t)Cc * tub * p * p;
+  const int64_t chunks = K_pad >> 3;
+  const int64_t total = B * tokens * chunks;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / chunks;
+    const int64_t k0 = (idx - row * chunks) << 3;
+    const int64_t b = row / tokens;
+    int64_t tkn = row - b * tokens;
+    const int ft = (int)(tkn / (gh * gw)); tkn -= (int64_t)ft * gh * gw;
+    const int py = (int)(tkn / gw), px = (int)(tkn - (int64_t)py * gw);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t k = k0 + e;
+      float v = 0.f;
+      if (k < K) {
+        int64_t r = k;
+        const int dx = (int)(r % p); r /= p;
+        const int dy = (int)(r % p); r /= p;
+        const int dt = (int)(r % tub);
+        const int c = (int)(r / tub);
+        v = pix[(((b * F + (int64_t)ft * tub + dt) * Cc + c) * H + (int64_t)py * p + dy) * W + (int64_t)px * p + dx];
+      }
+      o[e] = f32_to_bf16(v);
+    }
+    *(u16x8_t*)(out + row * K_pad + k0) = o;
   }
 }
 
@@ -365,6 +416,7 @@ extern "C" int tribe_rotary_fwd(uint16_t* x, int64_t rows, int64_t T, int64_t ro
   TRIBE_REQUIRE(rot_dim > 0 && rot_dim <= dim_head && rot_dim % 8 == 0 && dim_head % 8 == 0,
                 "tribe_rotary_fwd: rot_dim=%d must be a multiple of 8 and <= dim_head=%d (dim_head %% 8 == 0)", rot_dim, dim_head);
   TRIBE_REQUIRE(row_stride >= (int64_t)n_heads * dim_head && row_stride % 8 == 0, "tribe_rotary_fwd: bad row stride");
+  TRIBE_REQUIRE(interleaved >= 0 && interleaved <= 2, "tribe_rotary_fwd: interleaved must be 0, 1 or 2");
   const int64_t total = rows * n_heads * (rot_dim / 8);
   hipLaunchKernelGGL(rotary_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, T, row_stride, n_heads,
                      dim_head, rot_dim, cos_tab, sin_tab, interleaved);
@@ -414,6 +466,22 @@ extern "C" int tribe_embedding_fwd(const void* table, int32_t table_dtype, const
                        dim, vocab, x);
   else
     TRIBE_REQUIRE(false, "tribe_embedding_fwd: table dtype must be f32 or bf16");
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_im2col3d_fwd(const float* pixels, int64_t B, int32_t frames, int32_t chans, int32_t height, int32_t width,
+                                  int32_t tubelet, int32_t patch, uint16_t* out, int64_t K_pad, void* stream) {
+  TRIBE_REQUIRE(pixels && out, "tribe_im2col3d_fwd: null pointer");
+  TRIBE_REQUIRE(B > 0 && frames > 0 && chans > 0 && tubelet > 0 && patch > 0 && frames % tubelet == 0 && height % patch == 0 &&
+                    width % patch == 0,
+                "tribe_im2col3d_fwd: frames / height / width must be multiples of the tubelet / patch size");
+  const int64_t K = (int64_t)chans * tubelet * patch * patch;
+  TRIBE_REQUIRE(K_pad >= K && K_pad % 8 == 0, "tribe_im2col3d_fwd: K_pad=%lld must be >= %lld and a multiple of 8", (long long)K_pad,
+                (long long)K);
+  const int64_t tokens = (int64_t)(frames / tubelet) * (height / patch) * (width / patch);
+  hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(B * tokens * (K_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream, pixels, B, frames,
+                     chans, height, width, tubelet, patch, out, K_pad);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

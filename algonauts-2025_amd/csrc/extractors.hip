@@ -129,3 +129,117 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
   }
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// tribe_vjepa2_fwd: transformers VJEPA2Model encoder (data_utils/features/video.py:239-274 -> modeling_vjepa2.py
+// VJEPA2Encoder: Conv3d tubelet patch embedding -> depth x [LayerNorm -> q/k/v Linear(+bias) -> 3-D rotary ->
+// bidirectional attention -> proj + residual -> LayerNorm -> fc1 + GELU -> fc2 + residual]); every hidden state
+// (embeddings + each layer output, NOT the final LayerNorm) is averaged over tokens (video.py:228).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct VitPlan {
+  int64_t tokens, M;
+  size_t x_b, xn_b, qkv_b, ao_b, act_b, col_b;
+};
+inline VitPlan vit_plan(const tribe_vjepa2_desc* d) {
+  VitPlan p;
+  p.tokens = (int64_t)(d->frames / d->tubelet) * (d->height / d->patch) * (d->width / d->patch);
+  p.M = d->B * p.tokens;
+  p.x_b = align256((size_t)p.M * d->dim * 4);
+  p.xn_b = align256((size_t)p.M * d->dim * 2);
+  p.qkv_b = align256((size_t)p.M * 3 * d->dim * 2);
+  p.ao_b = align256((size_t)p.M * d->dim * 2);
+  p.act_b = align256((size_t)p.M * d->mlp * 2);
+  p.col_b = align256((size_t)p.M * d->K_pad * 2);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t tribe_vjepa2_workspace_bytes(const tribe_vjepa2_desc* d) {
+  if (!d || d->B <= 0 || d->tubelet <= 0 || d->patch <= 0) return 0;
+  const VitPlan p = vit_plan(d);
+  const size_t tail = p.act_b > p.col_b ? p.act_b : p.col_b;  // the im2col buffer is dead once the embedding GEMM ran
+  return p.x_b + p.xn_b + p.qkv_b + p.ao_b + tail;
+}
+
+extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream) {
+  TRIBE_REQUIRE(d && states && workspace, "tribe_vjepa2_fwd: null pointer");
+  TRIBE_REQUIRE(d->B > 0 && d->dim > 0 && d->depth >= 0 && d->heads > 0 && d->mlp > 0, "tribe_vjepa2_fwd: bad shape");
+  TRIBE_REQUIRE(d->heads * d->dim_head == d->dim && d->dim % 64 == 0 && d->mlp % 64 == 0 && d->K_pad % 64 == 0,
+                "tribe_vjepa2_fwd: dim = heads * dim_head, and dim / mlp / K_pad must be multiples of 64");
+  TRIBE_REQUIRE(d->pixels && d->w_patch && d->cos_tab && d->sin_tab && (d->depth == 0 || d->layers_host),
+                "tribe_vjepa2_fwd: missing parameter pointer");
+  TRIBE_REQUIRE(((uintptr_t)workspace % 256) == 0 && workspace_bytes >= tribe_vjepa2_workspace_bytes(d),
+                "tribe_vjepa2_fwd: workspace too small or misaligned");
+  const VitPlan p = vit_plan(d);
+  char* w = (char*)workspace;
+  float* x = (float*)w; w += p.x_b;
+  uint16_t* xn = (uint16_t*)w; w += p.xn_b;
+  uint16_t* qkv = (uint16_t*)w; w += p.qkv_b;
+  uint16_t* ao = (uint16_t*)w; w += p.ao_b;
+  uint16_t* act = (uint16_t*)w;
+  uint16_t* col = (uint16_t*)w;
+  const int64_t M = p.M, dim = d->dim, BD = d->B * dim;
+
+  int rc = tribe_im2col3d_fwd(d->pixels, d->B, d->frames, d->chans, d->height, d->width, d->tubelet, d->patch, col, d->K_pad, stream);
+  if (rc) return rc;
+  tribe_gemm_desc g = gemm_zero();
+  g.M = M; g.N = dim; g.K = d->K_pad;
+  g.A = col; g.lda = d->K_pad; g.B = d->w_patch; g.ldb = d->K_pad;
+  g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.role = TRIBE_ROLE_PROJECTOR;
+  if (d->b_patch) { g.bias = d->b_patch; g.bias_mode = TRIBE_BIAS_COL; }
+  rc = tribe_gemm_bf16(&g, stream);
+  if (rc) return rc;
+  rc = tribe_segment_mean_fwd(x, d->B, p.tokens, dim, nullptr, nullptr, states, dim, stream);
+  if (rc) return rc;
+
+  for (int l = 0; l < d->depth; ++l) {
+    const tribe_vit_layer& L = d->layers_host[l];
+    TRIBE_REQUIRE(L.norm1_w && L.w_qkv && L.w_proj && L.norm2_w && L.w_fc1 && L.w_fc2, "tribe_vjepa2_fwd: layer %d has a null parameter", l);
+    rc = tribe_layernorm_fwd(x, M, dim, L.norm1_w, L.norm1_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = 3 * dim; g.K = dim;
+    g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
+    g.C = qkv; g.ldc = 3 * dim; g.c_dtype = TRIBE_BF16; g.role = TRIBE_ROLE_QKV;
+    if (L.b_qkv) { g.bias = L.b_qkv; g.bias_mode = TRIBE_BIAS_COL; }
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    rc = tribe_rotary_fwd(qkv, M, p.tokens, 3 * dim, 2 * d->heads, d->dim_head, d->dim_head, d->cos_tab, d->sin_tab, 2, stream);
+    if (rc) return rc;
+    tribe_attention_desc a;
+    a.q = qkv; a.k = qkv + dim; a.v = qkv + 2 * dim;
+    a.ld_q = a.ld_k = a.ld_v = 3 * dim;
+    a.out = ao; a.ld_out = dim;
+    a.B = d->B; a.T = p.tokens; a.heads_q = d->heads; a.heads_kv = d->heads; a.dim_head = d->dim_head; a.causal = 0;
+    a.scale = 1.0f / sqrtf((float)d->dim_head);
+    rc = tribe_attention_fwd_ex(&a, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = dim; g.K = dim;
+    g.A = ao; g.lda = dim; g.B = L.w_proj; g.ldb = dim;
+    g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_OUT_PROJ;
+    if (L.b_proj) { g.bias = L.b_proj; g.bias_mode = TRIBE_BIAS_COL; }
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    rc = tribe_layernorm_fwd(x, M, dim, L.norm2_w, L.norm2_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = d->mlp; g.K = dim;
+    g.A = xn; g.lda = dim; g.B = L.w_fc1; g.ldb = dim;
+    g.C = act; g.ldc = d->mlp; g.c_dtype = TRIBE_BF16; g.act = TRIBE_ACT_GELU; g.role = TRIBE_ROLE_FF1;
+    if (L.b_fc1) { g.bias = L.b_fc1; g.bias_mode = TRIBE_BIAS_COL; }
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = dim; g.K = d->mlp;
+    g.A = act; g.lda = d->mlp; g.B = L.w_fc2; g.ldb = d->mlp;
+    g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_FF2;
+    if (L.b_fc2) { g.bias = L.b_fc2; g.bias_mode = TRIBE_BIAS_COL; }
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    rc = tribe_segment_mean_fwd(x, d->B, p.tokens, dim, nullptr, nullptr, states + (int64_t)(l + 1) * BD, dim, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}

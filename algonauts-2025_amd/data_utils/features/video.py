@@ -1,0 +1,111 @@
+"""V-JEPA2 (ViT-g) video feature extractor on MI355X HIP kernels.
+
+Mirror of the reference plugin `VJEPA2` / `VideoModel` (/root/reference/data_utils/data_utils/features/video.py:56-274):
+for every 0.5 s step a clip of 64 frames covering the previous 4 s (video.py:203-224) goes through the HF video
+processor and `VJEPA2Model(..., output_hidden_states=True)` (video.py:247-268); the 41 hidden states are stacked and
+averaged over the 8192 tokens (video.py:228) -> `[41, 1408]` per step.  Here the encoder forward and the token mean run
+in one C call (`tribe_vjepa2_fwd`); the predictor head, whose output the reference discards, is not run.
+Frame decoding and the HF processor (resize / rescale / normalise) stay on the host (SURVEY: moviepy decode is out of
+scope); the boundary is the processor's `pixel_values_videos` f32 [B, frames, 3, H, W].
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import typing as tp
+
+import torch
+
+from tribe_hip import ops
+from tribe_hip._lib import Vjepa2Desc, VitLayer, check, lib
+
+# facebook/vjepa2-vitg-fpc64-256 hyper-parameters (public model card; configuration input, not verifiable offline)
+VJEPA2_VITG_FPC64_256 = dict(patch_size=16, crop_size=256, frames_per_clip=64, tubelet_size=2, hidden_size=1408, in_chans=3,
+                             num_attention_heads=22, num_hidden_layers=40, mlp_ratio=48 / 11, layer_norm_eps=1e-6, qkv_bias=True)
+
+
+def rope3d_tables(grid_depth: int, grid_size: int, dim_head: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """Per-element cos / sin tables [tokens, dim_head] of VJEPA2RopeAttention (modeling_vjepa2.py:180-294): the head is
+    split into three segments of 2*((dim_head//3)//2) dims rotated by the frame / height / width index of the token;
+    inside a segment of D dims element j uses frequency 10000^(-(j mod D/2)/(D/2)) (the library TILES its frequencies,
+    `repeat(1,1,1,2)`, while pairing (2i, 2i+1)); remaining dims are passed through (cos 1, sin 0)."""
+    seg = 2 * ((dim_head // 3) // 2)
+    ids = torch.arange(grid_depth * grid_size * grid_size)
+    tpf = grid_size * grid_size
+    frame = ids // tpf
+    height = (ids - tpf * frame) // grid_size
+    width = (ids - tpf * frame) - grid_size * height
+    omega = 1.0 / 10000 ** (torch.arange(seg // 2, dtype=torch.float32) / (seg / 2.0))
+    cos = torch.ones(ids.numel(), dim_head)
+    sin = torch.zeros(ids.numel(), dim_head)
+    for k, pos in enumerate((frame, height, width)):
+        freq = pos.float()[:, None] * omega[None, :]  # [tokens, seg/2]
+        cos[:, k * seg:(k + 1) * seg] = freq.cos().repeat(1, 2)
+        sin[:, k * seg:(k + 1) * seg] = freq.sin().repeat(1, 2)
+    return cos.contiguous(), sin.contiguous()
+
+
+class HipVJEPA2Encoder:
+    def __init__(self, config: tp.Any, state_dict: dict[str, torch.Tensor], device: str | torch.device = "cuda"):
+        g = (lambda k: config[k]) if isinstance(config, dict) else (lambda k: getattr(config, k))
+        self.patch, self.crop, self.frames, self.tubelet = g("patch_size"), g("crop_size"), g("frames_per_clip"), g("tubelet_size")
+        self.dim, self.chans, self.heads, self.depth = g("hidden_size"), g("in_chans"), g("num_attention_heads"), g("num_hidden_layers")
+        self.mlp = int(self.dim * g("mlp_ratio"))
+        self.eps = float(g("layer_norm_eps"))
+        self.dim_head = self.dim // self.heads
+        self.device = dev = torch.device(device)
+        sd = {k.removeprefix("encoder."): v for k, v in state_dict.items() if not k.startswith("predictor.")}
+
+        def f32(name: str) -> torch.Tensor | None:
+            return sd[name].detach().to(device=dev, dtype=torch.float32).contiguous() if name in sd else None
+
+        self.keep: list[torch.Tensor] = []
+
+        def own(t: torch.Tensor | None) -> int | None:
+            if t is None:
+                return None
+            self.keep.append(t)
+            return t.data_ptr()
+
+        wp = f32("embeddings.patch_embeddings.proj.weight")  # [dim, C, tub, p, p]
+        self.w_patch = ops.pack_weight(wp.reshape(self.dim, -1).contiguous())
+        self.b_patch = f32("embeddings.patch_embeddings.proj.bias")
+        self.layers = (VitLayer * max(self.depth, 1))()
+        for i in range(self.depth):
+            p = f"layer.{i}."
+            L = self.layers[i]
+            wqkv = torch.cat([f32(p + "attention.query.weight"), f32(p + "attention.key.weight"), f32(p + "attention.value.weight")])
+            bq = f32(p + "attention.query.bias")
+            L.norm1_w, L.norm1_b = own(f32(p + "norm1.weight")), own(f32(p + "norm1.bias"))
+            L.w_qkv = own(ops.pack_weight(wqkv))
+            L.b_qkv = own(torch.cat([bq, f32(p + "attention.key.bias"), f32(p + "attention.value.bias")])) if bq is not None else None
+            L.w_proj, L.b_proj = own(ops.pack_weight(f32(p + "attention.proj.weight"))), own(f32(p + "attention.proj.bias"))
+            L.norm2_w, L.norm2_b = own(f32(p + "norm2.weight")), own(f32(p + "norm2.bias"))
+            L.w_fc1, L.b_fc1 = own(ops.pack_weight(f32(p + "mlp.fc1.weight"))), own(f32(p + "mlp.fc1.bias"))
+            L.w_fc2, L.b_fc2 = own(ops.pack_weight(f32(p + "mlp.fc2.weight"))), own(f32(p + "mlp.fc2.bias"))
+        self._tabs: dict[tuple[int, int], tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def hidden_state_means(self, pixel_values_videos: torch.Tensor) -> torch.Tensor:
+        """pixel_values_videos f32 [B, frames, C, H, W] -> f32 [B, depth + 1, dim] (video.py:262-268 + :228)."""
+        pix = pixel_values_videos.to(device=self.device, dtype=torch.float32).contiguous()
+        B, F, Cc, H, W = pix.shape
+        if Cc != self.chans or F % self.tubelet or H % self.patch or W % self.patch:
+            raise ValueError(f"unexpected clip shape {tuple(pix.shape)}")
+        key = (F // self.tubelet, H // self.patch)
+        if H != W:
+            raise ValueError("square frames expected (crop_size x crop_size)")
+        if key not in self._tabs:
+            cos, sin = rope3d_tables(key[0], key[1], self.dim_head)
+            self._tabs[key] = (cos.to(self.device), sin.to(self.device))
+        cos, sin = self._tabs[key]
+        d = Vjepa2Desc()
+        d.B, d.frames, d.chans, d.height, d.width, d.tubelet, d.patch = B, F, Cc, H, W, self.tubelet, self.patch
+        d.dim, d.depth, d.heads, d.dim_head, d.mlp, d.ln_eps = self.dim, self.depth, self.heads, self.dim_head, self.mlp, self.eps
+        d.w_patch, d.b_patch, d.K_pad = self.w_patch.data_ptr(), ops._p(self.b_patch), self.w_patch.shape[1]
+        d.layers_host = C.cast(self.layers, C.POINTER(VitLayer))
+        d.cos_tab, d.sin_tab, d.pixels = cos.data_ptr(), sin.data_ptr(), pix.data_ptr()
+        states = torch.empty(self.depth + 1, B, self.dim, dtype=torch.float32, device=self.device)
+        ws = ops.workspace(lib().tribe_vjepa2_workspace_bytes(C.byref(d)), self.device, "extractor")
+        check(lib().tribe_vjepa2_fwd(C.byref(d), states.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+              "tribe_vjepa2_fwd")
+        return states.transpose(0, 1).contiguous()

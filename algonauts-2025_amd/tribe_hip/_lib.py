@@ -73,6 +73,27 @@ class LlamaDesc(C.Structure):
     ]
 
 
+class VitLayer(C.Structure):
+    """struct tribe_vit_layer"""
+
+    _fields_ = [(n, vp) for n in ("norm1_w", "norm1_b", "w_qkv", "b_qkv", "w_proj", "b_proj", "norm2_w", "norm2_b", "w_fc1", "b_fc1",
+                                  "w_fc2", "b_fc2")]
+
+
+class Vjepa2Desc(C.Structure):
+    """struct tribe_vjepa2_desc"""
+
+    _fields_ = [
+        ("B", i64),
+        ("frames", i32), ("chans", i32), ("height", i32), ("width", i32), ("tubelet", i32), ("patch", i32),
+        ("dim", i32), ("depth", i32), ("heads", i32), ("dim_head", i32), ("mlp", i32),
+        ("ln_eps", f32),
+        ("w_patch", vp), ("b_patch", vp), ("K_pad", i64),
+        ("layers_host", C.POINTER(VitLayer)),
+        ("cos_tab", vp), ("sin_tab", vp), ("pixels", vp),
+    ]
+
+
 class EncoderLayer(C.Structure):
     """struct tribe_encoder_layer"""
 
@@ -115,6 +136,9 @@ SIGNATURES = {
     "tribe_rmsnorm_fwd": (C.c_int, [vp, i64, i64, vp, f32, vp, i32, vp]),
     "tribe_layernorm_fwd": (C.c_int, [vp, i64, i64, vp, vp, f32, vp, i32, vp]),
     "tribe_segment_mean_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
+    "tribe_im2col3d_fwd": (C.c_int, [vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
+    "tribe_vjepa2_workspace_bytes": (sz, [C.POINTER(Vjepa2Desc)]),
+    "tribe_vjepa2_fwd": (C.c_int, [C.POINTER(Vjepa2Desc), vp, vp, sz, vp]),
     "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
     "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),

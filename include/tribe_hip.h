@@ -131,6 +131,8 @@ int tribe_scalenorm_fwd(const float* x, int64_t rows, int64_t dim, const float* 
  * row_stride elements (a fused qkv buffer: q heads followed by k heads).  Position of row r is r % T.
  * cos/sin: f32 [T, rot_dim/2]; interleaved != 0 pairs (2i,2i+1) (x_transformers 2.x), else (i, i+rot_dim/2)
  * (x_transformers 1.27 and HF rotate_half, modeling_llama.py). */
+/* interleaved == 2: per-ELEMENT tables f32 [T, rot_dim] with (2i, 2i+1) pairs -- out[2i] = x[2i] C[2i] - x[2i+1] S[2i],
+ * out[2i+1] = x[2i+1] C[2i+1] + x[2i] S[2i+1] (VJEPA2RopeAttention.apply_rotary_embeddings, modeling_vjepa2.py:180-294) */
 int tribe_rotary_fwd(uint16_t* x, int64_t rows, int64_t T, int64_t row_stride, int32_t n_heads, int32_t dim_head,
                      int32_t rot_dim, const float* cos_tab, const float* sin_tab, int32_t interleaved, void* stream);
 /* softmax(q k^T * scale) v for all (batch, head); qkv as above; out bf16 [rows, heads*dim_head] */
@@ -198,6 +200,36 @@ int tribe_layernorm_fwd(const float* x, int64_t rows, int64_t dim, const float* 
  * non-pad positions; video.py:228: mean over all tokens).  x f32 [B*T, dim] -> out f32, row stride ld_out. */
 int tribe_segment_mean_fwd(const float* x, int64_t B, int64_t T, int64_t dim, const int64_t* start, const int64_t* len,
                            float* out, int64_t ld_out, void* stream);
+
+/* Conv3d patch embedding with stride == kernel (VJEPA2PatchEmbeddings3D, modeling_vjepa2.py:84-117) as im2col:
+ * pixels f32 [B, frames, chans, H, W] -> bf16 [B * tokens, K_pad], K = chans*tubelet*patch*patch in Conv3d weight order */
+int tribe_im2col3d_fwd(const float* pixels, int64_t B, int32_t frames, int32_t chans, int32_t height, int32_t width,
+                       int32_t tubelet, int32_t patch, uint16_t* out, int64_t K_pad, void* stream);
+
+typedef struct tribe_vit_layer {
+  const float* norm1_w; const float* norm1_b;
+  const uint16_t* w_qkv; const float* b_qkv;   /* bf16 [3*dim, dim] rows q | k | v, f32 [3*dim] */
+  const uint16_t* w_proj; const float* b_proj; /* bf16 [dim, dim] */
+  const float* norm2_w; const float* norm2_b;
+  const uint16_t* w_fc1; const float* b_fc1;   /* bf16 [mlp, dim] */
+  const uint16_t* w_fc2; const float* b_fc2;   /* bf16 [dim, mlp] */
+} tribe_vit_layer;
+
+typedef struct tribe_vjepa2_desc {
+  int64_t B;                                   /* clips */
+  int32_t frames, chans, height, width, tubelet, patch;
+  int32_t dim, depth, heads, dim_head, mlp;
+  float ln_eps;
+  const uint16_t* w_patch; const float* b_patch; int64_t K_pad;  /* bf16 [dim, K_pad] */
+  const tribe_vit_layer* layers_host;          /* HOST array [depth] */
+  const float* cos_tab; const float* sin_tab;  /* f32 [tokens, dim_head] per-element 3-D rope tables */
+  const float* pixels;                         /* f32 [B, frames, chans, H, W] (output of the HF video processor) */
+} tribe_vjepa2_desc;
+
+size_t tribe_vjepa2_workspace_bytes(const tribe_vjepa2_desc* d);
+/* VJEPA2Model encoder forward with output_hidden_states (video.py:247-274), fused with the token mean of
+ * video.py:228: states f32 [depth + 1, B, dim] (state 0 = patch embeddings, state l = output of layer l). */
+int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream);
 
 typedef struct tribe_llama_layer {
   const float* input_norm_w;     /* [dim] */

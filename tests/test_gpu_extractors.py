@@ -116,3 +116,47 @@ def test_llama_word_states_vs_transformers(shape):
         np.testing.assert_allclose(got[0, j], want[j][0], rtol=0, atol=4e-3 * np.abs(want[j][0]).max() + 1e-6)  # bf16 embedding table
         err = _rel(got[:, j], want[j])
         assert err < 1.5e-2, f"word {j}: relative L2 error {err:.2e}"
+
+
+def _tiny_vjepa2(hidden=128, heads=2, layers=3, mlp_ratio=4.0, crop=64, frames=8):
+    from transformers import VJEPA2Config, VJEPA2Model
+
+    cfg = VJEPA2Config(patch_size=16, crop_size=crop, frames_per_clip=frames, tubelet_size=2, hidden_size=hidden, in_chans=3,
+                       num_attention_heads=heads, num_hidden_layers=layers, mlp_ratio=mlp_ratio, pred_hidden_size=64,
+                       pred_num_attention_heads=2, pred_num_hidden_layers=1, pred_num_mask_tokens=2)
+    torch.manual_seed(0)
+    return cfg, VJEPA2Model(cfg).eval()
+
+
+@pytest.mark.parametrize("shape", ["tiny", "vitg_width"])
+def test_vjepa2_hidden_state_means_vs_transformers(shape):
+    """video.py:262-268 (stack of output_hidden_states) + :228 (mean over tokens) vs tribe_vjepa2_fwd.
+    'vitg_width' uses the ViT-g widths (1408, 22 heads x 64, MLP 6144) on 2 layers and a small clip."""
+    from data_utils.features.video import HipVJEPA2Encoder
+
+    cfg, hf = _tiny_vjepa2() if shape == "tiny" else _tiny_vjepa2(hidden=1408, heads=22, layers=2, mlp_ratio=48 / 11, crop=96, frames=4)
+    g = torch.Generator().manual_seed(2)
+    clips = torch.randn(2, cfg.frames_per_clip, 3, cfg.crop_size, cfg.crop_size, generator=g)
+    with torch.no_grad():
+        out = hf(pixel_values_videos=clips, output_hidden_states=True, skip_predictor=True)
+    want = torch.cat([x.unsqueeze(1) for x in out.hidden_states], dim=1).mean(dim=2)  # [B, n_states, dim]
+    enc = HipVJEPA2Encoder(cfg, hf.state_dict())
+    got = enc.hidden_state_means(clips).cpu()
+    assert got.shape == want.shape == (2, cfg.num_hidden_layers + 1, cfg.hidden_size)
+    for s in range(want.shape[1]):
+        err = _rel(got[:, s], want[:, s])
+        assert err < 2e-2, f"state {s}: relative L2 error {err:.2e}"
+
+
+def test_rope3d_tables_match_transformers():
+    """The per-element tables reproduce VJEPA2RopeAttention.apply_rotary_embeddings (modeling_vjepa2.py:279-294)."""
+    from data_utils.features.video import rope3d_tables
+
+    cfg, hf = _tiny_vjepa2()
+    attn = hf.encoder.layer[0].attention
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(1, 2, 64, 64, generator=g)  # [B, heads, tokens, dim_head]
+    want = attn.apply_rotary_embeddings(q, attn.get_position_ids(torch.zeros(1, 64, 128)))
+    cos, sin = rope3d_tables(4, 4, 64)
+    rot = torch.stack((-q[..., 1::2], q[..., 0::2]), dim=-1).flatten(-2)
+    torch.testing.assert_close(q * cos + rot * sin, want, rtol=1e-5, atol=1e-6)
