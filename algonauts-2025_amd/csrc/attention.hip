@@ -57,11 +57,13 @@ struct AttnArgs {
   int T, heads_q, group;  // group = heads_q / heads_kv
   float scale_log2e;
   int qblocks;
+  // relative_key position bias (Wav2Vec2BertSelfAttention, modeling_wav2vec2_bert.py:308-320): score += q . E[clamp(j - i)]
+  const float* qe; int64_t ld_qe; int qe_stride_h; int rel_left, rel_right;  // qe[row][h * stride + clamp(j-i, -left, right) + left]
 };
 
 // CAUSAL: key <= query (HF LlamaAttention.is_causal, modeling_llama.py); a wave skips key tiles that lie entirely
 // above its 16 query rows, the workgroup stops at the last tile its 128 rows can see.
-template <int DH, int CAUSAL>
+template <int DH, int CAUSAL, int RELKEY>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
   using C = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,6 +173,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int key_base = t * C::KV + 4 * fq;
     float sv[8];
     float pmax = -INFINITY;
+    if (RELKEY) {
+      const float* qrow_e = a.qe + ((int64_t)b * T + qrow) * a.ld_qe + h * a.qe_stride_h + a.rel_left;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int d0 = key_base + r - qrow, d1 = key_base + 16 + r - qrow;
+        d0 = d0 < -a.rel_left ? -a.rel_left : (d0 > a.rel_right ? a.rel_right : d0);
+        d1 = d1 < -a.rel_left ? -a.rel_left : (d1 > a.rel_right ? a.rel_right : d1);
+        s0[r] += qrow_e[d0];
+        s1[r] += qrow_e[d1];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int lim = CAUSAL ? ((q0 + l15 + 1 < T) ? q0 + l15 + 1 : T) : T;  // first masked key for this lane's query
@@ -237,25 +250,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
-template <int DH, int CAUSAL>
+template <int DH, int CAUSAL, int RELKEY>
 int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
   using C = AttnCfg<DH>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, CAUSAL, RELKEY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     attr_done = true;
   }
   const int64_t nblocks = B * a.heads_q * a.qblocks;
   if (nblocks >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: grid too large"); return -1; }
   if ((int64_t)a.T * a.ld_kv >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: sequence too long for 32-bit offsets"); return -1; }
-  hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL>), dim3((unsigned)nblocks), dim3(512), C::SMEM, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, RELKEY>), dim3((unsigned)nblocks), dim3(512), C::SMEM, s, a);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }
 
 template <int DH>
 int launch_attn_dh(const AttnArgs& a, int64_t B, int causal, hipStream_t s) {
-  return causal ? launch_attn<DH, 1>(a, B, s) : launch_attn<DH, 0>(a, B, s);
+  return causal ? launch_attn<DH, 1, 0>(a, B, s) : launch_attn<DH, 0, 0>(a, B, s);
 }
 
 }  // namespace
@@ -281,7 +294,15 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
   a.T = (int)d->T; a.heads_q = d->heads_q; a.group = d->heads_q / d->heads_kv;
   a.scale_log2e = d->scale * 1.4426950408889634f;
   a.qblocks = (int)((d->T + 127) / 128);
+  a.qe = d->rel_qe; a.ld_qe = d->ld_rel_qe; a.qe_stride_h = d->rel_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
   hipStream_t s = (hipStream_t)stream;
+  if (d->rel_qe) {
+    TRIBE_REQUIRE(d->dim_head == 64 && !d->causal, "tribe_attention_fwd_ex: the relative_key bias is built for dim_head 64, non-causal");
+    TRIBE_REQUIRE(d->rel_left >= 0 && d->rel_right >= 0 && d->rel_stride_h >= d->rel_left + d->rel_right + 1 &&
+                      d->ld_rel_qe >= (int64_t)d->heads_q * d->rel_stride_h,
+                  "tribe_attention_fwd_ex: bad relative_key table geometry");
+    return launch_attn<64, 0, 1>(a, d->B, s);
+  }
   switch (d->dim_head) {
     case 64: return launch_attn_dh<64>(a, d->B, d->causal, s);
     case 128: return launch_attn_dh<128>(a, d->B, d->causal, s);
@@ -298,5 +319,6 @@ int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, in
   d.ld_q = d.ld_k = d.ld_v = 3 * inner;
   d.out = out; d.ld_out = inner;
   d.B = B; d.T = T; d.heads_q = heads; d.heads_kv = heads; d.dim_head = dim_head; d.causal = 0; d.scale = scale;
+  d.rel_qe = nullptr; d.ld_rel_qe = 0; d.rel_stride_h = 0; d.rel_left = d.rel_right = 0;
   return tribe_attention_fwd_ex(&d, (void*)s);
 }

@@ -250,6 +250,79 @@ __global__ __launch_bounds__(256) void im2col3d_kernel(const float* __restrict__
   }
 }
 
+// causal depthwise Conv1d (left padding K-1) over time + LayerNorm over channels + swish, one workgroup per (b, t) row
+// (Wav2Vec2BertConvolutionModule, modeling_wav2vec2_bert.py:214-222).  x bf16 [B*T, C]; w f32 [K, C] (tap-major so that
+// a thread's 4 channels are one float4); output bf16 [B*T, C].  The 31 input rows of a window are L2 hits.
+template <int MAXG>
+__global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const unsigned short* __restrict__ x, int64_t T, int C, int K,
+                                                              const float* __restrict__ w, const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b, float eps,
+                                                              unsigned short* __restrict__ y) {
+  __shared__ float red[8];
+  const int64_t row = blockIdx.x;  // b * T + t
+  const int64_t t = row % T;
+  const int groups = C >> 2;
+  float acc[MAXG][4];
+  float s1 = 0.f;
+#pragma unroll
+  for (int gi = 0; gi < MAXG; ++gi) {
+    const int cg = threadIdx.x + gi * 256;
+    acc[gi][0] = acc[gi][1] = acc[gi][2] = acc[gi][3] = 0.f;
+    if (cg < groups) {
+      for (int k = 0; k < K; ++k) {
+        const int64_t tt = t - (K - 1) + k;
+        if (tt < 0) continue;
+        const u16x4_t xv = *(const u16x4_t*)(x + (row - t + tt) * C + cg * 4);
+        const float4 wv = *(const float4*)(w + (int64_t)k * C + cg * 4);
+        acc[gi][0] += bf16_to_f32(xv[0]) * wv.x; acc[gi][1] += bf16_to_f32(xv[1]) * wv.y;
+        acc[gi][2] += bf16_to_f32(xv[2]) * wv.z; acc[gi][3] += bf16_to_f32(xv[3]) * wv.w;
+      }
+      s1 += acc[gi][0] + acc[gi][1] + acc[gi][2] + acc[gi][3];
+    }
+  }
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  const float mean = block_sum(s1) / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int gi = 0; gi < MAXG; ++gi)
+    if (threadIdx.x + gi * 256 < groups)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = acc[gi][e] - mean; s2 += d * d; }
+  const float rstd = rsqrtf(block_sum(s2) / (float)C + eps);
+#pragma unroll
+  for (int gi = 0; gi < MAXG; ++gi) {
+    const int cg = threadIdx.x + gi * 256;
+    if (cg < groups) {
+      const float4 g = *(const float4*)(ln_w + cg * 4), b = *(const float4*)(ln_b + cg * 4);
+      const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+      u16x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = (acc[gi][e] - mean) * rstd * gg[e] + bb[e];
+        o[e] = f32_to_bf16(v / (1.0f + __expf(-v)));  // swish
+      }
+      *(u16x4_t*)(y + row * C + cg * 4) = o;
+    }
+  }
+}
+
+// out[b][i][:] = x[b*T + idx[i]][:]   (F.interpolate(mode="nearest") along time = a row gather, audio.py:163-171)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int64_t T, int64_t dim,
+                                                          const int64_t* __restrict__ idx, int64_t n, float* __restrict__ out) {
+  const int64_t b = blockIdx.y, i = blockIdx.x;
+  int64_t t = idx[i];
+  t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+  const float4* src = (const float4*)(x + (b * T + t) * dim);
+  float4* dst = (float4*)(out + (b * n + i) * dim);
+  for (int64_t c = threadIdx.x; c < (dim >> 2); c += blockDim.x) dst[c] = src[c];
+}
+
 // embedding gather: one wave per token row
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_kernel(const T* __restrict__ table, const int64_t* __restrict__ ids, int64_t n,
@@ -482,6 +555,29 @@ extern "C" int tribe_im2col3d_fwd(const float* pixels, int64_t B, int32_t frames
   const int64_t tokens = (int64_t)(frames / tubelet) * (height / patch) * (width / patch);
   hipLaunchKernelGGL(im2col3d_kernel, dim3(grid_for(B * tokens * (K_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream, pixels, B, frames,
                      chans, height, width, tubelet, patch, out, K_pad);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_dwconv_ln_swish_fwd(const uint16_t* x, int64_t B, int64_t T, int32_t C, int32_t K, const float* w_kc,
+                                         const float* ln_w, const float* ln_b, float eps, uint16_t* y, void* stream) {
+  TRIBE_REQUIRE(x && w_kc && ln_w && ln_b && y, "tribe_dwconv_ln_swish_fwd: null pointer");
+  TRIBE_REQUIRE(B > 0 && T > 0 && C > 0 && K > 0 && C % 4 == 0 && C <= 4096, "tribe_dwconv_ln_swish_fwd: C=%d must be a multiple of 4, <= 4096", C);
+  TRIBE_REQUIRE(B * T < (1ll << 31), "tribe_dwconv_ln_swish_fwd: too many rows");
+  dim3 grid((unsigned)(B * T));
+  if (C <= 1024)
+    hipLaunchKernelGGL(dwconv_ln_swish_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, T, C, K, w_kc, ln_w, ln_b, eps, y);
+  else
+    hipLaunchKernelGGL(dwconv_ln_swish_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, T, C, K, w_kc, ln_w, ln_b, eps, y);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_gather_rows_fwd(const float* x, int64_t B, int64_t T, int64_t dim, const int64_t* idx, int64_t n, float* out,
+                                     void* stream) {
+  TRIBE_REQUIRE(x && idx && out, "tribe_gather_rows_fwd: null pointer");
+  TRIBE_REQUIRE(B > 0 && T > 0 && dim > 0 && dim % 4 == 0 && n > 0 && B < 65536, "tribe_gather_rows_fwd: bad shape");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, T, dim, idx, n, out);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

@@ -94,6 +94,7 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
     a.B = d->B; a.T = d->T; a.heads_q = d->heads_q; a.heads_kv = d->heads_kv; a.dim_head = d->dim_head;
     a.causal = 1;  // right padding + causal mask: real tokens never see pad keys, pad rows are never pooled
     a.scale = 1.0f / sqrtf((float)d->dim_head);
+    a.rel_qe = nullptr; a.ld_rel_qe = 0; a.rel_stride_h = 0; a.rel_left = a.rel_right = 0;
     rc = tribe_attention_fwd_ex(&a, stream);
     if (rc) return rc;
     g = gemm_zero();
@@ -213,6 +214,7 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
     a.out = ao; a.ld_out = dim;
     a.B = d->B; a.T = p.tokens; a.heads_q = d->heads; a.heads_kv = d->heads; a.dim_head = d->dim_head; a.causal = 0;
     a.scale = 1.0f / sqrtf((float)d->dim_head);
+    a.rel_qe = nullptr; a.ld_rel_qe = 0; a.rel_stride_h = 0; a.rel_left = a.rel_right = 0;
     rc = tribe_attention_fwd_ex(&a, stream);
     if (rc) return rc;
     g = gemm_zero();
@@ -239,6 +241,171 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     rc = tribe_segment_mean_fwd(x, d->B, p.tokens, dim, nullptr, nullptr, states + (int64_t)(l + 1) * BD, dim, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tribe_w2vbert_fwd: transformers Wav2Vec2BertModel (data_utils/features/audio.py:253-263 -> modeling_wav2vec2_bert.py):
+// feature projection (LayerNorm + Linear), then depth x conformer block [half-step FFN (swish) -> self-attention with
+// "relative_key" position bias -> convolution module (pointwise + GLU, causal depthwise k=31, LayerNorm, swish,
+// pointwise) -> half-step FFN -> LayerNorm]; every hidden state is resampled along time by row gather
+// (F.interpolate nearest, audio.py:163-171).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct W2vPlan {
+  int64_t M, qe_ld;
+  size_t x_b, xn_b, wide_b, qe_b, ao_b, glu_b, feat_b, featp_b;
+};
+inline W2vPlan w2v_plan(const tribe_w2vbert_desc* d) {
+  W2vPlan p;
+  p.M = d->B * d->T;
+  const int npos = d->rel_left + d->rel_right + 1;
+  p.qe_ld = (int64_t)d->heads * ((npos + 7) / 8 * 8);
+  p.x_b = align256((size_t)p.M * d->dim * 4);
+  p.xn_b = align256((size_t)p.M * d->dim * 2);
+  const int64_t wide = d->inter > 3 * d->dim ? d->inter : 3 * d->dim;
+  p.wide_b = align256((size_t)p.M * wide * 2);
+  p.qe_b = align256((size_t)p.M * p.qe_ld * 4);
+  p.ao_b = align256((size_t)p.M * d->dim * 2);
+  p.glu_b = align256((size_t)p.M * d->dim * 2);
+  p.feat_b = align256((size_t)p.M * d->feat_dim * 4);
+  p.featp_b = align256((size_t)p.M * d->feat_pad * 2);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t tribe_w2vbert_workspace_bytes(const tribe_w2vbert_desc* d) {
+  if (!d || d->B <= 0 || d->T <= 0) return 0;
+  const W2vPlan p = w2v_plan(d);
+  return p.x_b + p.xn_b + p.wide_b + p.qe_b + p.ao_b + p.glu_b + p.feat_b + p.featp_b;
+}
+
+extern "C" int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream) {
+  TRIBE_REQUIRE(d && states && workspace, "tribe_w2vbert_fwd: null pointer");
+  TRIBE_REQUIRE(d->B > 0 && d->T > 0 && d->dim > 0 && d->depth >= 0 && d->heads > 0 && d->inter > 0 && d->n_out > 0, "tribe_w2vbert_fwd: bad shape");
+  TRIBE_REQUIRE(d->heads * d->dim_head == d->dim && d->dim_head == 64, "tribe_w2vbert_fwd: head size must be 64 (relative_key attention kernel)");
+  TRIBE_REQUIRE(d->dim % 64 == 0 && d->inter % 64 == 0 && d->feat_pad % 64 == 0 && d->feat_pad >= d->feat_dim && d->feat_dim % 4 == 0,
+                "tribe_w2vbert_fwd: dim / inter / feat_pad must be multiples of 64");
+  TRIBE_REQUIRE(d->features && d->fp_ln_w && d->fp_ln_b && d->w_fp && d->out_index && (d->depth == 0 || d->layers_host),
+                "tribe_w2vbert_fwd: missing parameter pointer");
+  TRIBE_REQUIRE(((uintptr_t)workspace % 256) == 0 && workspace_bytes >= tribe_w2vbert_workspace_bytes(d),
+                "tribe_w2vbert_fwd: workspace too small or misaligned");
+  const W2vPlan p = w2v_plan(d);
+  char* w = (char*)workspace;
+  float* x = (float*)w; w += p.x_b;
+  uint16_t* xn = (uint16_t*)w; w += p.xn_b;
+  uint16_t* wide = (uint16_t*)w; w += p.wide_b;   // FFN hidden  |  qkv
+  float* qe = (float*)w; w += p.qe_b;
+  uint16_t* ao = (uint16_t*)w; w += p.ao_b;
+  uint16_t* glu = (uint16_t*)w; w += p.glu_b;
+  float* feat = (float*)w; w += p.feat_b;
+  uint16_t* featp = (uint16_t*)w;
+  const int64_t M = p.M, dim = d->dim;
+  const int64_t state_sz = d->B * d->n_out * dim;
+  const int npos = d->rel_left + d->rel_right + 1;
+  const int qe_stride_h = (npos + 7) / 8 * 8;
+
+  // feature projection: LayerNorm(feat_dim) -> Linear
+  int rc = tribe_layernorm_fwd(d->features, M, d->feat_dim, d->fp_ln_w, d->fp_ln_b, d->ln_eps, feat, TRIBE_F32, stream);
+  if (rc) return rc;
+  rc = tribe_pack_weight_bf16(feat, M, d->feat_dim, d->feat_dim, featp, M, d->feat_pad, stream);  // cast + zero-pad K
+  if (rc) return rc;
+  tribe_gemm_desc g = gemm_zero();
+  g.M = M; g.N = dim; g.K = d->feat_pad;
+  g.A = featp; g.lda = d->feat_pad; g.B = d->w_fp; g.ldb = d->feat_pad;
+  g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.role = TRIBE_ROLE_PROJECTOR;
+  if (d->b_fp) { g.bias = d->b_fp; g.bias_mode = TRIBE_BIAS_COL; }
+  rc = tribe_gemm_bf16(&g, stream);
+  if (rc) return rc;
+  rc = tribe_gather_rows_fwd(x, d->B, d->T, dim, d->out_index, d->n_out, states, stream);
+  if (rc) return rc;
+
+  auto ffn = [&](const float* ln_w, const float* ln_b, const uint16_t* w_in, const float* b_in, const uint16_t* w_out,
+                 const float* b_out_half) -> int {
+    int r = tribe_layernorm_fwd(x, M, dim, ln_w, ln_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    if (r) return r;
+    tribe_gemm_desc q = gemm_zero();
+    q.M = M; q.N = d->inter; q.K = dim;
+    q.A = xn; q.lda = dim; q.B = w_in; q.ldb = dim;
+    q.C = wide; q.ldc = d->inter; q.c_dtype = TRIBE_BF16; q.act = TRIBE_ACT_SILU; q.role = TRIBE_ROLE_FF1;
+    if (b_in) { q.bias = b_in; q.bias_mode = TRIBE_BIAS_COL; }
+    r = tribe_gemm_bf16(&q, stream);
+    if (r) return r;
+    q = gemm_zero();  // x = 0.5 * (h W^T + b) + x
+    q.M = M; q.N = dim; q.K = d->inter;
+    q.A = wide; q.lda = d->inter; q.B = w_out; q.ldb = d->inter;
+    q.C = x; q.ldc = dim; q.c_dtype = TRIBE_F32; q.alpha = 0.5f; q.res = x; q.ldres = dim; q.role = TRIBE_ROLE_FF2;
+    if (b_out_half) { q.bias = b_out_half; q.bias_mode = TRIBE_BIAS_COL; }
+    return tribe_gemm_bf16(&q, stream);
+  };
+
+  for (int l = 0; l < d->depth; ++l) {
+    const tribe_conformer_layer& L = d->layers_host[l];
+    TRIBE_REQUIRE(L.ffn1_ln_w && L.w_ffn1_in && L.w_ffn1_out && L.attn_ln_w && L.w_qkv && L.dist_emb && L.w_attn_out && L.conv_ln_w &&
+                      L.w_pw1 && L.w_dw_kc && L.dw_ln_w && L.w_pw2 && L.ffn2_ln_w && L.w_ffn2_in && L.w_ffn2_out && L.final_ln_w,
+                  "tribe_w2vbert_fwd: layer %d has a null parameter", l);
+    // 1. half-step feed-forward
+    rc = ffn(L.ffn1_ln_w, L.ffn1_ln_b, L.w_ffn1_in, L.b_ffn1_in, L.w_ffn1_out, L.b_ffn1_out_half);
+    if (rc) return rc;
+    // 2. self-attention with relative_key bias
+    rc = tribe_layernorm_fwd(x, M, dim, L.attn_ln_w, L.attn_ln_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    if (rc) return rc;
+    uint16_t* qkv = wide;
+    g = gemm_zero();
+    g.M = M; g.N = 3 * dim; g.K = dim;
+    g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
+    g.C = qkv; g.ldc = 3 * dim; g.c_dtype = TRIBE_BF16; g.role = TRIBE_ROLE_QKV;
+    if (L.b_qkv) { g.bias = L.b_qkv; g.bias_mode = TRIBE_BIAS_COL; }
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    g = gemm_zero();  // qe[row][h][p] = q[row][h][:] . dist_emb[p][:]
+    g.M = M; g.N = npos; g.K = d->dim_head; g.batch0 = d->heads;
+    g.A = qkv; g.lda = 3 * dim; g.sA0 = d->dim_head;
+    g.B = L.dist_emb; g.ldb = d->dim_head; g.sB0 = 0;
+    g.C = qe; g.ldc = p.qe_ld; g.sC0 = qe_stride_h; g.c_dtype = TRIBE_F32; g.role = TRIBE_ROLE_ATTN_SCORES;
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    tribe_attention_desc a;
+    a.q = qkv; a.k = qkv + dim; a.v = qkv + 2 * dim;
+    a.ld_q = a.ld_k = a.ld_v = 3 * dim;
+    a.out = ao; a.ld_out = dim;
+    a.B = d->B; a.T = d->T; a.heads_q = d->heads; a.heads_kv = d->heads; a.dim_head = d->dim_head; a.causal = 0;
+    a.scale = 1.0f / sqrtf((float)d->dim_head);
+    a.rel_qe = qe; a.ld_rel_qe = p.qe_ld; a.rel_stride_h = qe_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
+    rc = tribe_attention_fwd_ex(&a, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = dim; g.K = dim;
+    g.A = ao; g.lda = dim; g.B = L.w_attn_out; g.ldb = dim;
+    g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_OUT_PROJ;
+    if (L.b_attn_out) { g.bias = L.b_attn_out; g.bias_mode = TRIBE_BIAS_COL; }
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    // 3. convolution module
+    rc = tribe_layernorm_fwd(x, M, dim, L.conv_ln_w, L.conv_ln_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = 2 * dim; g.K = dim;
+    g.A = xn; g.lda = dim; g.B = L.w_pw1; g.ldb = dim;
+    g.C = glu; g.ldc = dim; g.c_dtype = TRIBE_BF16; g.act = TRIBE_ACT_GLU; g.role = TRIBE_ROLE_GENERIC;
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    rc = tribe_dwconv_ln_swish_fwd(glu, d->B, d->T, (int32_t)dim, d->conv_kernel, L.w_dw_kc, L.dw_ln_w, L.dw_ln_b, d->ln_eps, xn, stream);
+    if (rc) return rc;
+    g = gemm_zero();
+    g.M = M; g.N = dim; g.K = dim;
+    g.A = xn; g.lda = dim; g.B = L.w_pw2; g.ldb = dim;
+    g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_GENERIC;
+    rc = tribe_gemm_bf16(&g, stream);
+    if (rc) return rc;
+    // 4. half-step feed-forward, then the block's final LayerNorm (in place on the residual stream)
+    rc = ffn(L.ffn2_ln_w, L.ffn2_ln_b, L.w_ffn2_in, L.b_ffn2_in, L.w_ffn2_out, L.b_ffn2_out_half);
+    if (rc) return rc;
+    rc = tribe_layernorm_fwd(x, M, dim, L.final_ln_w, L.final_ln_b, d->ln_eps, x, TRIBE_F32, stream);
+    if (rc) return rc;
+    rc = tribe_gather_rows_fwd(x, d->B, d->T, dim, d->out_index, d->n_out, states + (int64_t)(l + 1) * state_sz, stream);
     if (rc) return rc;
   }
   return 0;

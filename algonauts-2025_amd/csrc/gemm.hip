@@ -414,9 +414,9 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
                     d->sB0 % 8 == 0,
                 "tribe_gemm_bf16: lda/ldb/batch strides must be multiples of 8 elements (16-byte rows)");
   TRIBE_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "tribe_gemm_bf16: A/B must be 16-byte aligned");
-  TRIBE_REQUIRE(d->lda >= d->K && d->ldb >= d->K && d->ldc >= (d->act == TRIBE_ACT_SWIGLU ? d->N / 2 : d->N),
+  TRIBE_REQUIRE(d->lda >= d->K && d->ldb >= d->K && d->ldc >= ((d->act == TRIBE_ACT_SWIGLU || d->act == TRIBE_ACT_GLU) ? d->N / 2 : d->N),
                 "tribe_gemm_bf16: leading dimension too small");
-  TRIBE_REQUIRE(d->act != TRIBE_ACT_SWIGLU || (d->N % 2 == 0 && !d->res && !d->rowadd && !d->gadd && d->bias_mode != TRIBE_BIAS_ROW),
+  TRIBE_REQUIRE((d->act != TRIBE_ACT_SWIGLU && d->act != TRIBE_ACT_GLU) || (d->N % 2 == 0 && !d->res && !d->rowadd && !d->gadd && d->bias_mode != TRIBE_BIAS_ROW),
                 "tribe_gemm_bf16: SWIGLU needs an even N and no residual / row adds");
   TRIBE_REQUIRE(d->c_dtype == TRIBE_F32 || d->c_dtype == TRIBE_BF16, "tribe_gemm_bf16: c_dtype must be f32 or bf16");
   TRIBE_REQUIRE(d->bias_mode == TRIBE_BIAS_NONE || d->bias != nullptr, "tribe_gemm_bf16: bias_mode set without bias");

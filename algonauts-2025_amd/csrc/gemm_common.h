@@ -50,6 +50,10 @@ __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
 }
 
+__device__ __forceinline__ float sigmoid_f(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
+}
+
 // quad-lane exchanges as DPP moves (no LDS traffic): lane i <- lane i^1 / i^2 within each group of 4
 __device__ __forceinline__ float quad_xor1(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -117,9 +121,12 @@ __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const 
       const float4 b = *(const float4*)(c.bias + n);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (g.act == TRIBE_ACT_SWIGLU) {
-      // (gate, up) column pairs -> two outputs at columns n/2, n/2 + 1 of a C that is N/2 wide (LlamaMLP, modeling_llama.py:177)
-      const float o0 = silu_f(v[0]) * v[1], o1 = silu_f(v[2]) * v[3];
+    if (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU) {
+      // column pairs -> two outputs at columns n/2, n/2 + 1 of a C that is N/2 wide:
+      // SwiGLU silu(gate) * up (LlamaMLP, modeling_llama.py:177); GLU a * sigmoid(b) (nn.GLU in the conformer conv module)
+      const bool glu = g.act == TRIBE_ACT_GLU;
+      const float o0 = glu ? v[0] * sigmoid_f(v[1]) : silu_f(v[0]) * v[1];
+      const float o1 = glu ? v[2] * sigmoid_f(v[3]) : silu_f(v[2]) * v[3];
       const int64_t oidx = c.c_off + m * g.ldc + (n >> 1);
       if (OUT_BF16) {
         const unsigned int pk = (unsigned int)f32_to_bf16(o0) | ((unsigned int)f32_to_bf16(o1) << 16);
@@ -163,13 +170,13 @@ __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const 
     }
     return;
   }
-  if (g.act == TRIBE_ACT_SWIGLU) {
+  if (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU) {
 #pragma unroll
     for (int k = 0; k < 4; k += 2) {
       if (n + k + 1 >= g.N) break;
       float gate = v[k], up = v[k + 1];
       if (g.bias_mode == TRIBE_BIAS_COL) { gate += c.bias[n + k]; up += c.bias[n + k + 1]; }
-      const float o = silu_f(gate) * up;
+      const float o = (g.act == TRIBE_ACT_GLU) ? gate * sigmoid_f(up) : silu_f(gate) * up;
       const int64_t oidx = c.c_off + m * g.ldc + ((n + k) >> 1);
       if (OUT_BF16) ((unsigned short*)c.C)[oidx] = f32_to_bf16(o);
       else ((float*)c.C)[oidx] = o;

@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libtribe_hip.so"
 
 F32, BF16, F64 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU, ACT_GLU = 0, 1, 2, 3, 4
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head"]
 
@@ -50,6 +50,7 @@ class AttentionDesc(C.Structure):
         ("q", vp), ("k", vp), ("v", vp), ("ld_q", i64), ("ld_k", i64), ("ld_v", i64),
         ("out", vp), ("ld_out", i64), ("B", i64), ("T", i64),
         ("heads_q", i32), ("heads_kv", i32), ("dim_head", i32), ("causal", i32), ("scale", f32),
+        ("rel_qe", vp), ("ld_rel_qe", i64), ("rel_stride_h", i32), ("rel_left", i32), ("rel_right", i32),
     ]
 
 
@@ -91,6 +92,29 @@ class Vjepa2Desc(C.Structure):
         ("w_patch", vp), ("b_patch", vp), ("K_pad", i64),
         ("layers_host", C.POINTER(VitLayer)),
         ("cos_tab", vp), ("sin_tab", vp), ("pixels", vp),
+    ]
+
+
+class ConformerLayer(C.Structure):
+    """struct tribe_conformer_layer"""
+
+    _fields_ = [(n, vp) for n in (
+        "ffn1_ln_w", "ffn1_ln_b", "w_ffn1_in", "b_ffn1_in", "w_ffn1_out", "b_ffn1_out_half",
+        "attn_ln_w", "attn_ln_b", "w_qkv", "b_qkv", "dist_emb", "w_attn_out", "b_attn_out",
+        "conv_ln_w", "conv_ln_b", "w_pw1", "w_dw_kc", "dw_ln_w", "dw_ln_b", "w_pw2",
+        "ffn2_ln_w", "ffn2_ln_b", "w_ffn2_in", "b_ffn2_in", "w_ffn2_out", "b_ffn2_out_half", "final_ln_w", "final_ln_b")]
+
+
+class W2vBertDesc(C.Structure):
+    """struct tribe_w2vbert_desc"""
+
+    _fields_ = [
+        ("B", i64), ("T", i64), ("feat_dim", i32), ("feat_pad", i32),
+        ("dim", i32), ("depth", i32), ("heads", i32), ("dim_head", i32), ("inter", i32), ("conv_kernel", i32),
+        ("rel_left", i32), ("rel_right", i32), ("ln_eps", f32),
+        ("fp_ln_w", vp), ("fp_ln_b", vp), ("w_fp", vp), ("b_fp", vp),
+        ("layers_host", C.POINTER(ConformerLayer)),
+        ("features", vp), ("out_index", vp), ("n_out", i64),
     ]
 
 
@@ -139,6 +163,10 @@ SIGNATURES = {
     "tribe_im2col3d_fwd": (C.c_int, [vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "tribe_vjepa2_workspace_bytes": (sz, [C.POINTER(Vjepa2Desc)]),
     "tribe_vjepa2_fwd": (C.c_int, [C.POINTER(Vjepa2Desc), vp, vp, sz, vp]),
+    "tribe_dwconv_ln_swish_fwd": (C.c_int, [vp, i64, i64, i32, i32, vp, vp, vp, f32, vp, vp]),
+    "tribe_gather_rows_fwd": (C.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
+    "tribe_w2vbert_workspace_bytes": (sz, [C.POINTER(W2vBertDesc)]),
+    "tribe_w2vbert_fwd": (C.c_int, [C.POINTER(W2vBertDesc), vp, vp, sz, vp]),
     "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
     "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),

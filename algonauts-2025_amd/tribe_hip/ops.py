@@ -77,7 +77,7 @@ def gemm_nt(
         raise ValueError(f"gemm_nt: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
     Z, M, K = a3.shape
     N = b3.shape[1]
-    n_out = N // 2 if act == "swiglu" else N  # SwiGLU folds (gate, up) column pairs
+    n_out = N // 2 if act in ("swiglu", "glu") else N  # SwiGLU / GLU fold adjacent column pairs
     if out is None:
         out = torch.empty((Z, M, n_out) if a.ndim == 3 else (M, n_out), dtype=out_dtype, device=a.device)
     _cuda(out, (torch.float32, torch.bfloat16), "out")
@@ -92,7 +92,7 @@ def gemm_nt(
     if bias is not None:
         _cuda(bias, torch.float32, "bias")
         d.bias, d.bias_mode = bias.data_ptr(), (_lib.BIAS_ROW if bias_row else _lib.BIAS_COL)
-    d.act = {"gelu": _lib.ACT_GELU, "swiglu": _lib.ACT_SWIGLU, "silu": _lib.ACT_SILU, None: _lib.ACT_NONE}[act]
+    d.act = {"gelu": _lib.ACT_GELU, "swiglu": _lib.ACT_SWIGLU, "silu": _lib.ACT_SILU, "glu": _lib.ACT_GLU, None: _lib.ACT_NONE}[act]
     if res is not None:
         _cuda(res, torch.float32, "res")
         d.res, d.ldres, d.sRes1 = res.data_ptr(), N, M * N

@@ -37,7 +37,8 @@ enum tribe_act {
   TRIBE_ACT_NONE = 0,
   TRIBE_ACT_GELU = 1,   /* exact (erf) GELU */
   TRIBE_ACT_SWIGLU = 2, /* columns come in (gate, up) pairs: out[:, j] = silu(v[:, 2j]) * v[:, 2j+1]; C has N/2 columns */
-  TRIBE_ACT_SILU = 3
+  TRIBE_ACT_SILU = 3,
+  TRIBE_ACT_GLU = 4     /* (a, b) column pairs: out[:, j] = v[:, 2j] * sigmoid(v[:, 2j+1]); C has N/2 columns (nn.GLU) */
 };
 enum tribe_bias_mode { TRIBE_BIAS_NONE = 0, TRIBE_BIAS_COL = 1, TRIBE_BIAS_ROW = 2 };
 /* which operator of the path a GEMM launch serves: selects the kernel SYMBOL (per-operator rows in
@@ -152,6 +153,10 @@ typedef struct tribe_attention_desc {
   int64_t B, T;
   int32_t heads_q, heads_kv, dim_head, causal;
   float scale;
+  /* optional "relative_key" position bias (Wav2Vec2BertSelfAttention, modeling_wav2vec2_bert.py:308-320):
+   * score[i][j] += rel_qe[b*T + i][h * rel_stride_h + clamp(j - i, -rel_left, rel_right) + rel_left], where
+   * rel_qe = q . distance_embedding^T (f32, computed by a GEMM beforehand).  NULL = none.  dim_head 64 only. */
+  const float* rel_qe; int64_t ld_rel_qe; int32_t rel_stride_h, rel_left, rel_right;
 } tribe_attention_desc;
 int tribe_attention_fwd_ex(const tribe_attention_desc* desc, void* stream);
 
@@ -230,6 +235,50 @@ size_t tribe_vjepa2_workspace_bytes(const tribe_vjepa2_desc* d);
 /* VJEPA2Model encoder forward with output_hidden_states (video.py:247-274), fused with the token mean of
  * video.py:228: states f32 [depth + 1, B, dim] (state 0 = patch embeddings, state l = output of layer l). */
 int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream);
+
+/* causal depthwise Conv1d over time (left pad K-1, no bias) + LayerNorm over channels + swish
+ * (Wav2Vec2BertConvolutionModule, modeling_wav2vec2_bert.py:214-222).  x, y bf16 [B*T, C]; w_kc f32 [K, C] (tap-major). */
+int tribe_dwconv_ln_swish_fwd(const uint16_t* x, int64_t B, int64_t T, int32_t C, int32_t K, const float* w_kc,
+                              const float* ln_w, const float* ln_b, float eps, uint16_t* y, void* stream);
+/* out[b, i, :] = x[b*T + idx[i], :]  (nearest-neighbour F.interpolate along time, audio.py:163-171) */
+int tribe_gather_rows_fwd(const float* x, int64_t B, int64_t T, int64_t dim, const int64_t* idx, int64_t n, float* out,
+                          void* stream);
+
+typedef struct tribe_conformer_layer {
+  const float* ffn1_ln_w; const float* ffn1_ln_b;
+  const uint16_t* w_ffn1_in; const float* b_ffn1_in;     /* bf16 [inter, dim] */
+  const uint16_t* w_ffn1_out; const float* b_ffn1_out_half; /* bf16 [dim, inter]; bias pre-multiplied by 0.5 */
+  const float* attn_ln_w; const float* attn_ln_b;
+  const uint16_t* w_qkv; const float* b_qkv;             /* bf16 [3*dim, dim] */
+  const uint16_t* dist_emb;                              /* bf16 [left + right + 1, dim_head] */
+  const uint16_t* w_attn_out; const float* b_attn_out;   /* bf16 [dim, dim] */
+  const float* conv_ln_w; const float* conv_ln_b;
+  const uint16_t* w_pw1;                                 /* bf16 [2*dim, dim], rows interleaved (a_0, b_0, a_1, b_1, ...) for the GLU epilogue */
+  const float* w_dw_kc;                                  /* f32 [K, dim] depthwise taps, tap-major */
+  const float* dw_ln_w; const float* dw_ln_b;
+  const uint16_t* w_pw2;                                 /* bf16 [dim, dim] */
+  const float* ffn2_ln_w; const float* ffn2_ln_b;
+  const uint16_t* w_ffn2_in; const float* b_ffn2_in;
+  const uint16_t* w_ffn2_out; const float* b_ffn2_out_half;
+  const float* final_ln_w; const float* final_ln_b;
+} tribe_conformer_layer;
+
+typedef struct tribe_w2vbert_desc {
+  int64_t B, T;                       /* chunks x frames (no padding mask: the reference passes single unpadded chunks) */
+  int32_t feat_dim, feat_pad;         /* 160, padded to a multiple of 64 */
+  int32_t dim, depth, heads, dim_head, inter, conv_kernel, rel_left, rel_right;
+  float ln_eps;
+  const float* fp_ln_w; const float* fp_ln_b;            /* feature_projection.layer_norm */
+  const uint16_t* w_fp; const float* b_fp;               /* bf16 [dim, feat_pad] */
+  const tribe_conformer_layer* layers_host;              /* HOST array [depth] */
+  const float* features;              /* f32 [B*T, feat_dim] (output of the HF SeamlessM4T feature extractor) */
+  const int64_t* out_index; int64_t n_out;               /* frame index of every output time point (nearest interpolation) */
+} tribe_w2vbert_desc;
+
+size_t tribe_w2vbert_workspace_bytes(const tribe_w2vbert_desc* d);
+/* Wav2Vec2BertModel forward with output_hidden_states (audio.py:253-263) fused with the nearest-neighbour resampling
+ * to 2 Hz (audio.py:163-171): states f32 [depth + 1, B, n_out, dim]. */
+int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream);
 
 typedef struct tribe_llama_layer {
   const float* input_norm_w;     /* [dim] */

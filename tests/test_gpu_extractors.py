@@ -160,3 +160,50 @@ def test_rope3d_tables_match_transformers():
     cos, sin = rope3d_tables(4, 4, 64)
     rot = torch.stack((-q[..., 1::2], q[..., 0::2]), dim=-1).flatten(-2)
     torch.testing.assert_close(q * cos + rot * sin, want, rtol=1e-5, atol=1e-6)
+
+
+def _tiny_w2vbert(hidden=128, heads=2, layers=2, inter=256):
+    from transformers import Wav2Vec2BertConfig, Wav2Vec2BertModel
+
+    cfg = Wav2Vec2BertConfig(vocab_size=None, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                             intermediate_size=inter, feature_projection_input_dim=160, hidden_act="swish",
+                             position_embeddings_type="relative_key", left_max_position_embeddings=64,
+                             right_max_position_embeddings=8, conv_depthwise_kernel_size=31, add_adapter=False,
+                             use_intermediate_ffn_before_adapter=False, layerdrop=0.0, apply_spec_augment=False)
+    torch.manual_seed(0)
+    m = Wav2Vec2BertModel(cfg).eval()
+    with torch.no_grad():  # zero-initialised in HF; make the relative-position path carry signal
+        for layer in m.encoder.layers:
+            layer.self_attn.distance_embedding.weight.normal_(0, 0.5)
+    return cfg, m
+
+
+@pytest.mark.parametrize("shape", ["tiny", "w2v_width"])
+def test_w2vbert_hidden_states_vs_transformers(shape):
+    """audio.py:253-263 (stack + transpose of output_hidden_states) and :163-171 (nearest F.interpolate to 2 Hz) vs
+    tribe_w2vbert_fwd.  'w2v_width' uses the w2v-bert-2.0 widths (1024, 16 heads x 64, FFN 4096) on 2 layers."""
+    from data_utils.features.audio import HipWav2Vec2Bert
+
+    cfg, hf = _tiny_w2vbert() if shape == "tiny" else _tiny_w2vbert(hidden=1024, heads=16, layers=2, inter=4096)
+    g = torch.Generator().manual_seed(6)
+    T, n_out = 333, 13
+    feats = torch.randn(1, T, 160, generator=g)
+    with torch.no_grad():
+        out = hf(feats, output_hidden_states=True)
+    stacked = torch.stack(out.hidden_states).squeeze(1).transpose(-1, -2)  # [n_states, dim, T]  (audio.py:257-261)
+    want = torch.nn.functional.interpolate(stacked, n_out)  # audio.py:171
+    model = HipWav2Vec2Bert(cfg, hf.state_dict())
+    got = model.hidden_states_resampled(feats, n_out).cpu()[0]
+    assert got.shape == want.shape == (cfg.num_hidden_layers + 1, cfg.hidden_size, n_out)
+    for s in range(want.shape[0]):
+        err = _rel(got[s], want[s])
+        assert err < 2e-2, f"state {s}: relative L2 error {err:.2e}"
+
+
+def test_nearest_index_matches_interpolate():
+    from data_utils.features.audio import nearest_index
+
+    for t_in, t_out in ((3000, 120), (333, 13), (1499, 60), (7, 20)):
+        x = torch.arange(t_in, dtype=torch.float32)[None, None]
+        want = torch.nn.functional.interpolate(x, t_out)[0, 0].to(torch.int64)
+        assert torch.equal(nearest_index(t_in, t_out), want), (t_in, t_out)
