@@ -28,12 +28,15 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
+// keys per staged tile = 32 * NSUB: small heads take several 32-key sub-tiles per barrier / softmax pass so that the
+// fixed per-tile cost (barrier, max exchange, rescale test) is amortised over the same number of MFMAs as at DH = 384
 template <int DH>
 struct AttnCfg {
+  static constexpr int NSUB = DH <= 64 ? 4 : (DH <= 128 ? 2 : 1);
   static constexpr int KS = DH / 32;            // k-steps of S^T = K Q^T (16x16x32)
   static constexpr int DT = DH / 16;            // 16-row tiles of O^T
   static constexpr int ROWB = DH * 2;           // bytes per K / V tile row
-  static constexpr int KV = 32;                 // keys per tile
+  static constexpr int KV = 32 * NSUB;          // keys per staged tile
   static constexpr int TILE_BYTES = KV * ROWB;  // one K or V tile
   static constexpr int CHUNKS = DH / 8;         // 16-byte chunks per row
   static constexpr int WAVES = 8;
@@ -159,37 +162,46 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     const char* vt = kt + C::TILE_BYTES;
     if (!CAUSAL || t * C::KV <= q0 + 15) {  // wave-uniform: some key of this tile is visible to some row of this wave
 
-    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: two key tiles (keys 0-15, 16-31) share each Q fragment ----
-    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      const int off = k_rd[ks % KRD] + (ks / KRD) * SEG * 16;
-      const bf16x8_t ka = *(const bf16x8_t*)(kt + off);
-      const bf16x8_t kb2 = *(const bf16x8_t*)(kt + off + 16 * C::ROWB);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb2, qf[ks], s1, 0, 0, 0);
-    }
-    // accumulator map: s0[r] = S^T[key = 4 fq + r][q = l15], s1[r] = S^T[key = 16 + 4 fq + r][q]
-    const int key_base = t * C::KV + 4 * fq;
-    float sv[8];
+    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: per 32-key sub-tile two accumulators (keys 0-15, 16-31) share each Q fragment ----
+    float sv[C::NSUB][8];
     float pmax = -INFINITY;
-    if (RELKEY) {
-      const float* qrow_e = a.qe + ((int64_t)b * T + qrow) * a.ld_qe + h * a.qe_stride_h + a.rel_left;
+    const int lim = CAUSAL ? ((q0 + l15 + 1 < T) ? q0 + l15 + 1 : T) : T;  // first masked key for this lane's query
+#pragma unroll
+    for (int u = 0; u < C::NSUB; ++u) {
+      const int sub_key0 = t * C::KV + u * 32;
+      if (sub_key0 >= T || (CAUSAL && sub_key0 > q0 + 15)) {  // wave-uniform: nothing visible in this sub-tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[u][j] = -INFINITY;
+        continue;
+      }
+      f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int off = k_rd[ks % KRD] + (ks / KRD) * SEG * 16 + u * 32 * C::ROWB;
+        const bf16x8_t ka = *(const bf16x8_t*)(kt + off);
+        const bf16x8_t kb2 = *(const bf16x8_t*)(kt + off + 16 * C::ROWB);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb2, qf[ks], s1, 0, 0, 0);
+      }
+      // accumulator map: s0[r] = S^T[key = 4 fq + r][q = l15], s1[r] = S^T[key = 16 + 4 fq + r][q]
+      const int key_base = sub_key0 + 4 * fq;
+      if (RELKEY) {
+        const float* qrow_e = a.qe + ((int64_t)b * T + qrow) * a.ld_qe + h * a.qe_stride_h + a.rel_left;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int d0 = key_base + r - qrow, d1 = key_base + 16 + r - qrow;
+          d0 = d0 < -a.rel_left ? -a.rel_left : (d0 > a.rel_right ? a.rel_right : d0);
+          d1 = d1 < -a.rel_left ? -a.rel_left : (d1 > a.rel_right ? a.rel_right : d1);
+          s0[r] += qrow_e[d0];
+          s1[r] += qrow_e[d1];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int d0 = key_base + r - qrow, d1 = key_base + 16 + r - qrow;
-        d0 = d0 < -a.rel_left ? -a.rel_left : (d0 > a.rel_right ? a.rel_right : d0);
-        d1 = d1 < -a.rel_left ? -a.rel_left : (d1 > a.rel_right ? a.rel_right : d1);
-        s0[r] += qrow_e[d0];
-        s1[r] += qrow_e[d1];
+        sv[u][r] = (key_base + r < lim) ? s0[r] * scale_log2e : -INFINITY;
+        sv[u][4 + r] = (key_base + 16 + r < lim) ? s1[r] * scale_log2e : -INFINITY;
+        pmax = fmaxf(pmax, fmaxf(sv[u][r], sv[u][4 + r]));
       }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lim = CAUSAL ? ((q0 + l15 + 1 < T) ? q0 + l15 + 1 : T) : T;  // first masked key for this lane's query
-      sv[r] = (key_base + r < lim) ? s0[r] * scale_log2e : -INFINITY;
-      sv[4 + r] = (key_base + 16 + r < lim) ? s1[r] * scale_log2e : -INFINITY;
-      pmax = fmaxf(pmax, fmaxf(sv[r], sv[4 + r]));
     }
     // the other three 16-lane groups hold the other keys of this query
     pmax = fmaxf(pmax, __shfl_xor(pmax, 16, 64));
@@ -205,28 +217,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
     }
-    bf16x8_t pf;
+    bf16x8_t pf[C::NSUB];
     float psum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float p = __builtin_amdgcn_exp2f(sv[j] - m_run);
-      psum += p;
-      pf[j] = (short)f32_to_bf16(p);
-    }
+    for (int u = 0; u < C::NSUB; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float p = __builtin_amdgcn_exp2f(sv[u][j] - m_run);
+        psum += p;
+        pf[u][j] = (short)f32_to_bf16(p);
+      }
     l_run += psum;
 
     // ---- O^T[d][q] += sum_key V[key][d] P^T[key][q] ----
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) {
-      // d-tile dt covers columns 16 dt .. +15 = chunks 2 dt, 2 dt + 1
-      const int off = v_rd[dt % VRD] + (dt / VRD) * SEG * 16;
-      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vt + off));
-      const s16x4_t hi =
-          __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vt + off + 16 * C::ROWB));
-      bf16x8_t vf;
+    for (int u = 0; u < C::NSUB; ++u) {
+      const int sub_key0 = t * C::KV + u * 32;
+      if (sub_key0 >= T || (CAUSAL && sub_key0 > q0 + 15)) continue;  // P is all zero there
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      for (int dt = 0; dt < C::DT; ++dt) {
+        // d-tile dt covers columns 16 dt .. +15 = chunks 2 dt, 2 dt + 1
+        const int off = v_rd[dt % VRD] + (dt / VRD) * SEG * 16 + u * 32 * C::ROWB;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vt + off));
+        const s16x4_t hi =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vt + off + 16 * C::ROWB));
+        bf16x8_t vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], o[dt], 0, 0, 0);
+      }
     }
     }  // visible tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -50,7 +50,61 @@ def bench_llama():
               f"{per_tok * B * T / dt / 1e12:7.1f} TFLOP/s", flush=True)
 
 
+def _rand_sd(hf_cls, cfg_cls, kwargs):
+    """Random-weight state dict of a full-size HF architecture without building the module on the host twice."""
+    cfg = cfg_cls(**kwargs)
+    with torch.device("meta"):
+        m = hf_cls(cfg)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, v in m.state_dict().items():
+        if k.startswith("predictor."):
+            continue
+        if v.ndim >= 2:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.02
+        else:
+            sd[k] = torch.ones(v.shape) if "weight" in k else torch.zeros(v.shape)
+    return cfg, sd
+
+
+def bench_vjepa2():
+    from transformers import VJEPA2Config, VJEPA2Model
+
+    from data_utils.features.video import HipVJEPA2Encoder
+
+    cfg, sd = _rand_sd(VJEPA2Model, VJEPA2Config, dict(patch_size=16, crop_size=256, frames_per_clip=64, tubelet_size=2, hidden_size=1408,
+                                                        in_chans=3, num_attention_heads=22, num_hidden_layers=40, mlp_ratio=48 / 11,
+                                                        pred_hidden_size=64, pred_num_attention_heads=2, pred_num_hidden_layers=1))
+    enc = HipVJEPA2Encoder(cfg, sd)
+    H, L, mlp, tok = 1408, 40, int(1408 * 48 / 11), 8192
+    per_tok = L * (2 * H * 3 * H + 2 * H * H + 4 * H * mlp + 4 * tok * H)
+    for B in (1, 2):
+        clips = torch.randn(B, 64, 3, 256, 256, device="cuda")
+        dt = timed(lambda: enc.hidden_state_means(clips), n=3, warm=1)
+        print(f"vjepa2-vitg fwd+mean  clips={B} (8192 tokens each): {dt * 1e3:8.2f} ms  {B / dt:6.2f} clips/s  "
+              f"{per_tok * B * tok / dt / 1e12:7.1f} TFLOP/s", flush=True)
+
+
+def bench_w2vbert():
+    from transformers import Wav2Vec2BertConfig, Wav2Vec2BertModel
+
+    from data_utils.features.audio import HipWav2Vec2Bert
+
+    cfg, sd = _rand_sd(Wav2Vec2BertModel, Wav2Vec2BertConfig, dict(vocab_size=None, hidden_size=1024, num_hidden_layers=24,
+                                                                    num_attention_heads=16, intermediate_size=4096,
+                                                                    feature_projection_input_dim=160, add_adapter=False,
+                                                                    position_embeddings_type="relative_key"))
+    model = HipWav2Vec2Bert(cfg, sd)
+    H, L, I = 1024, 24, 4096
+    for B, T in ((1, 3000), (8, 3000)):
+        per_tok = L * (2 * 2 * 2 * H * I + 2 * H * 3 * H + 2 * H * H + 2 * H * 2 * H + 2 * H * H + 4 * T * H)
+        feats = torch.randn(B, T, 160, device="cuda")
+        dt = timed(lambda: model.hidden_states_resampled(feats, 120), n=3, warm=1)
+        print(f"w2v-bert-2.0 fwd+resample  chunks={B} x {T} frames (60 s): {dt * 1e3:8.2f} ms  {B * 60 / dt:8.1f} audio-s/s  "
+              f"{per_tok * B * T / dt / 1e12:7.1f} TFLOP/s", flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["llama"]
+    which = sys.argv[1:] or ["llama", "vjepa2", "w2vbert"]
     for w in which:
-        {"llama": bench_llama}[w]()
+        {"llama": bench_llama, "vjepa2": bench_vjepa2, "w2vbert": bench_w2vbert}[w]()
