@@ -92,22 +92,24 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const tribe_gemm_desc& g, int64_t
 // epi(...) -> C.  A 4x4 transpose inside each quad of lanes turns "4 rows x 1 column" per lane into
 // "1 row x 4 consecutive columns", so every lane issues ONE 16-byte (f32) / 8-byte (bf16) store and
 // reads its residual / bias operands as float4.
-template <int OUT_BF16>
-__device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t acc, int64_t mt0,
-                                                int64_t nt0, int lane) {
+// 4x4 transpose inside each quad of lanes: acc[r] = D[4*(lane>>4) + r][lane & 15] (MFMA C/D map) becomes
+// "row 4*(lane>>4) + (lane & 3), columns 4*((lane & 15) >> 2) .. +3" -- 4 consecutive columns of ONE row per lane.
+__device__ __forceinline__ void quad_transpose(f32x4_t acc, float alpha, int lane, float (&v)[4]) {
   const int a = lane & 3;
-  float v0 = acc[0] * g.alpha, v1 = acc[1] * g.alpha, v2 = acc[2] * g.alpha, v3 = acc[3] * g.alpha;
-  {
-    const bool b0 = a & 1, b1 = a & 2;
-    const float t0 = quad_xor1(b0 ? v0 : v1), t1 = quad_xor1(b0 ? v2 : v3);
-    if (b0) { v0 = t0; v2 = t1; } else { v1 = t0; v3 = t1; }
-    const float u0 = quad_xor2(b1 ? v0 : v2), u1 = quad_xor2(b1 ? v1 : v3);
-    if (b1) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
-  }
-  const int64_t m = mt0 + ((lane >> 4) << 2) + a;
-  const int64_t n = nt0 + (((lane & 15) >> 2) << 2);
+  float v0 = acc[0] * alpha, v1 = acc[1] * alpha, v2 = acc[2] * alpha, v3 = acc[3] * alpha;
+  const bool b0 = a & 1, b1 = a & 2;
+  const float t0 = quad_xor1(b0 ? v0 : v1), t1 = quad_xor1(b0 ? v2 : v3);
+  if (b0) { v0 = t0; v2 = t1; } else { v1 = t0; v3 = t1; }
+  const float u0 = quad_xor2(b1 ? v0 : v2), u1 = quad_xor2(b1 ? v1 : v3);
+  if (b1) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
+  v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
+}
+
+// epilogue of 4 consecutive columns n..n+3 of row m (values already scaled by alpha): bias, activation, residual,
+// row / gathered adds, store.
+template <int OUT_BF16>
+__device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const EpiCtx& c, float (&v)[4], int64_t m, int64_t n) {
   if (m >= g.M || n >= g.N) return;
-  float v[4] = {v0, v1, v2, v3};
   if (g.bias_mode == TRIBE_BIAS_ROW) {
     const float b = c.bias[m];
 #pragma unroll
@@ -199,4 +201,13 @@ __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const 
     if (OUT_BF16) ((unsigned short*)c.C)[idx + k] = f32_to_bf16(x);
     else ((float*)c.C)[idx + k] = x;
   }
+}
+
+// One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).
+template <int OUT_BF16>
+__device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t acc, int64_t mt0,
+                                                int64_t nt0, int lane) {
+  float v[4];
+  quad_transpose(acc, g.alpha, lane, v);
+  epilogue_row4<OUT_BF16>(g, c, v, mt0 + ((lane >> 4) << 2) + (lane & 3), nt0 + (((lane & 15) >> 2) << 2));
 }
