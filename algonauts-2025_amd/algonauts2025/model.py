@@ -172,9 +172,69 @@ class FmriEncoder(nn.Module):
         x, B, T = self._fused_embed(data, add_embeddings=True)
         return self.encoder.forward_tokens(x, B, T, out_dtype), B, T
 
-    @torch.no_grad()
+    # -- training path: same arithmetic, every op an autograd function whose forward AND backward are HIP kernels ----
+    def _wants_grad(self) -> bool:
+        # Lightning runs training_step in train mode with grad enabled; evaluation (.eval()) keeps the fused fast path
+        return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _forward_autograd(self, data: dict[str, torch.Tensor], pool_outputs: bool) -> torch.Tensor:
+        from modeling_utils import autograd as ag
+
+        cfg = self.config
+        if cfg.feature_aggregation != "cat":
+            raise NotImplementedError("the training path implements feature_aggregation='cat' (the reference default)")
+        for modality in data.keys():
+            if modality in self.feature_dims:
+                break
+        ref = data[modality]
+        B, T = ref.shape[0], ref.shape[-1]
+        n_mod, slot = len(self.feature_dims), self.hidden // len(self.feature_dims)
+        dropped = self._draw_modality_dropout()
+        slices = []
+        for m in self.feature_dims.keys():
+            if m not in self.projectors or m in dropped:  # model.py:143-144,158-159: zero block, no gradient
+                slices.append(torch.zeros(B * T, slot, dtype=torch.float32, device=ref.device))
+                continue
+            packed = ops.pack_features(data[m].contiguous(), layer_mean=cfg.layer_aggregation == "mean")
+            lin = self.projectors[m]
+            slices.append(ag.ProjectorFuse.apply(packed, lin.weight, lin.bias))
+        x = torch.cat(slices, dim=1).view(B, T, n_mod * slot)
+        x = x + self.time_pos_embed[:, :T]                      # model.py:169-170 (autograd sums the rows over the batch)
+        subject_id = data["subject_id"]
+        if hasattr(self, "subject_embed"):
+            x = x + self.subject_embed(subject_id)              # model.py:171-172
+        x = x.reshape(B * T, -1).contiguous()
+        enc = self.encoder
+        cos, sin = enc.packed().tables(T, x.device)
+        gs, eps = enc.final_norm.gain_scale, enc.final_norm.eps
+        scale = enc.dim_head**-0.5
+        for i in range(enc.depth):
+            norms_a, attn, res_a = enc.layers[2 * i]
+            norms_f, ff, res_f = enc.layers[2 * i + 1]
+            xn = ag.ScaleNorm.apply(x, norms_a[0].g, gs, eps)
+            wqkv = torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], dim=0)
+            qkv = ag.Linear.apply(xn, wqkv, None, None, None, False)
+            if enc.rotary_emb_dim:
+                qkv = ag.Rotary.apply(qkv, cos, sin, T, enc.heads, enc.dim_head, enc.rotary_emb_dim, enc.rotary_interleaved)
+            ao = ag.Attention.apply(qkv, B, T, enc.heads, enc.dim_head, scale)
+            x = ag.Linear.apply(ao, attn.to_out.weight, None, x, res_a.residual_scale, True)
+            xn = ag.ScaleNorm.apply(x, norms_f[0].g, gs, eps)
+            x = ag.FeedForward.apply(xn, ff.ff[0][0].weight, ff.ff[0][0].bias, ff.ff[2].weight, ff.ff[2].bias, x, res_f.residual_scale)
+        y = ag.ScaleNorm.apply(x, enc.final_norm.g, gs, eps)
+        out = ag.VoxelHead.apply(y.view(B, T, -1), self.predictor.weights, self.predictor.bias,
+                                 self.predictor.check_subjects(subject_id))
+        if pool_outputs and T != self.n_output_timesteps:
+            out = ag.AdaptivePool.apply(out, self.n_output_timesteps)
+        return out
+
     def forward(self, batch: SegmentData | dict, pool_outputs: bool = True) -> torch.Tensor:
         data = self._batch_dict(batch)
+        if self._wants_grad():
+            return self._forward_autograd(data, pool_outputs)
+        with torch.no_grad():
+            return self._forward_inference(data, pool_outputs)
+
+    def _forward_inference(self, data: dict[str, torch.Tensor], pool_outputs: bool = True) -> torch.Tensor:
         y, B, T = self._latents(data, torch.bfloat16)  # [B*T, hidden] bf16, final-normed
         out = self.predictor.forward_tokens(y.view(B, T, -1), data["subject_id"])  # [B, V, T] f32
         if pool_outputs and T != self.n_output_timesteps:  # AdaptiveAvgPool1d(T)(x[..., T]) is the identity

@@ -93,10 +93,12 @@ class BrainModule(nn.Module):
         self.on_val_or_test_epoch_end("test")
 
     def training_step(self, batch: SegmentData, batch_idx: int):
-        raise NotImplementedError(
-            "training_step needs the backward kernels (SURVEY.md section 8(f) rank 1); this round ships the forward / "
-            "evaluation path (validation_step, test_step, compute_multidim_pearson)."
-        )
+        """pl_module.py:126-128: returns the loss tensor; `loss.backward()` then runs the HIP backward kernels through
+        the autograd functions of modeling_utils/autograd.py (MSE loss, contrastive branch disabled)."""
+        if getattr(getattr(self.model, "config", None), "contrastive_enabled", False):
+            raise NotImplementedError("training with the contrastive branch is not built yet (SURVEY.md section 8(f))")
+        loss, _, _ = self._run_step(batch, batch_idx, step_name="train")
+        return loss
 
     def validation_step(self, batch: SegmentData, batch_idx: int):
         _, y_pred, y_true = self._run_step(batch, batch_idx, step_name="val")

@@ -1,0 +1,264 @@
+// Backward building blocks of the TRIBE path (pl_module.training_step -> loss.backward()): streaming kernels only;
+// the dense gradients are MFMA GEMMs (gemm.hip) fed with transposed bf16 operands produced here.  Roofline: HBM.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p);
+template <>
+__device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ldf<unsigned short>(const unsigned short* p) { return bf16_to_f32(*p); }
+
+// out[z][c][r] = in[z][r][c] (bf16), r zero-padded to R_pad; 64x64 tiles through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t R, int64_t C, int64_t s_z, int64_t s_r,
+                                                        unsigned short* __restrict__ out, int64_t so_z, int64_t R_pad) {
+  __shared__ unsigned short tile[64][66];
+  const int64_t z = blockIdx.z;
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const T* src = in + z * s_z;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? f32_to_bf16(ldf<T>(src + r * s_r + c)) : (unsigned short)0;
+  }
+  __syncthreads();
+  unsigned short* dst = out + z * so_z;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;
+    if (c < C && r < R_pad) dst[c * R_pad + r] = tile[tx][i];
+  }
+}
+
+// column sums: grid (N/256, slices); atomics into out
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, const float* __restrict__ b, int64_t M, int64_t N,
+                                                     int64_t ld, float* __restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+  const int64_t m0 = (int64_t)blockIdx.y * per, m1 = (m0 + per < M) ? m0 + per : M;
+  float acc = 0.f;
+  for (int64_t m = m0; m < m1; ++m) {
+    const float v = ldf<T>(a + m * ld + n);
+    acc += b ? v * b[m * ld + n] : v;
+  }
+  if (m0 < m1) atomicAdd(out + n, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scalenorm_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                            const float* __restrict__ g, float gain_scale, float eps, int64_t rows,
+                                                            int64_t dim, const float* __restrict__ dres, const float* __restrict__ rs,
+                                                            float* __restrict__ dx, float* __restrict__ dg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * dim;
+  const T* dyr = dy + row * dim;
+  float ss = 0.f, dot = 0.f;
+  for (int64_t i = lane; i < dim; i += 64) {
+    const float xv = xr[i];
+    ss += xv * xv;
+    dot += xv * ldf<T>(dyr + i);
+  }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float norm = sqrtf(ss);
+  const float s = g[0] * gain_scale;
+  // y = x * s / max(norm, eps): below eps the norm is a constant and the projection term vanishes
+  const bool clamped = norm < eps;
+  const float inv = 1.0f / fmaxf(norm, eps);
+  const float proj = clamped ? 0.f : dot * inv * inv;  // <xhat, dy> / norm
+  for (int64_t i = lane; i < dim; i += 64) {
+    float v = s * inv * (ldf<T>(dyr + i) - xr[i] * proj);
+    if (dres) v += dres[row * dim + i] * (rs ? rs[i] : 1.0f);
+    dx[row * dim + i] = v;
+  }
+  if (dg && lane == 0) atomicAdd(dg, gain_scale * dot * inv);
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* __restrict__ P, const float* __restrict__ dP,
+                                                          int64_t rows, int64_t T, int64_t T_pad, int64_t ld_p, int64_t ld_dp,
+                                                          float scale, unsigned short* __restrict__ dS, int64_t ld_ds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const unsigned short* p = P + row * ld_p;
+  const float* dp = dP + row * ld_dp;
+  float delta = 0.f;
+  for (int64_t i = lane; i < T; i += 64) delta += bf16_to_f32(p[i]) * dp[i];
+  delta = wave_sum(delta);
+  unsigned short* ds = dS + row * ld_ds;
+  for (int64_t i = lane; i < T_pad; i += 64)
+    ds[i] = (i < T) ? f32_to_bf16(bf16_to_f32(p[i]) * (dp[i] - delta) * scale) : (unsigned short)0;
+}
+
+__global__ void mse_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n, const float* __restrict__ gs,
+                               float* __restrict__ dp) {
+  const float k = gs[0] * 2.0f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dp[i] = k * (p[i] - t[i]);
+}
+
+__global__ void pool_bwd_kernel(const float* __restrict__ dy, int64_t rows, int64_t T_in, int64_t T_out, float* __restrict__ dx) {
+  const int64_t total = rows * T_in;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / T_in, t = idx - r * T_in;
+    // windows i with floor(i T_in / T_out) <= t < ceil((i+1) T_in / T_out)
+    int64_t i_lo = (t * T_out) / T_in - 1;  // windows before this one end at or before t
+    if (i_lo < 0) i_lo = 0;
+    float acc = 0.f;
+    for (int64_t i = i_lo; i < T_out; ++i) {
+      const int64_t a = (i * T_in) / T_out, b = ((i + 1) * T_in + T_out - 1) / T_out;
+      if (a > t) break;
+      if (t < b) acc += dy[r * T_out + i] / (float)(b - a);
+    }
+    dx[idx] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void rowsum_scatter_kernel(const float* __restrict__ x, int64_t B, int64_t V, int64_t T,
+                                                             const int64_t* __restrict__ idx, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // row = b * V + v
+  const int64_t b = row / V, v = row - b * V;
+  if (b >= B) return;
+  const float* p = x + row * T;
+  float acc = 0.f;
+  for (int64_t t = lane; t < T; t += 64) acc += p[t];
+  acc = wave_sum(acc);
+  if (lane == 0) atomicAdd(out + idx[b] * V + v, acc);
+}
+
+__global__ void scale_cols_kernel(const float* __restrict__ x, const float* __restrict__ rs, int64_t M, int64_t N, float* __restrict__ y) {
+  const int64_t total = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = rs ? x[i] * rs[i % N] : x[i];
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, int64_t n4, unsigned short* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = ((const float4*)x)[i];
+    u16x4_t o;
+    o[0] = f32_to_bf16(v.x); o[1] = f32_to_bf16(v.y); o[2] = f32_to_bf16(v.z); o[3] = f32_to_bf16(v.w);
+    ((u16x4_t*)y)[i] = o;
+  }
+}
+
+inline unsigned grid_for(int64_t total, int block) {
+  int64_t b = (total + block - 1) / block;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+int tribe_internal_softmax(const float* S, int64_t R, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p, hipStream_t stream);
+
+extern "C" int tribe_transpose_bf16(const void* in, int32_t in_dtype, int64_t Z, int64_t R, int64_t C, int64_t s_z, int64_t s_r,
+                                    uint16_t* out, int64_t so_z, int64_t R_pad, void* stream) {
+  TRIBE_REQUIRE(in && out, "tribe_transpose_bf16: null pointer");
+  TRIBE_REQUIRE(Z > 0 && R > 0 && C > 0 && R_pad >= R && s_r >= C && Z < 65536, "tribe_transpose_bf16: bad shape");
+  dim3 grid((unsigned)((R_pad + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)Z);
+  if (in_dtype == TRIBE_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, R, C, s_z, s_r, out, so_z, R_pad);
+  else if (in_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL(transpose_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, R, C, s_z,
+                       s_r, out, so_z, R_pad);
+  else
+    TRIBE_REQUIRE(false, "tribe_transpose_bf16: dtype must be f32 or bf16");
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_colsum_fwd(const void* a, int32_t a_dtype, const float* b, int64_t M, int64_t N, int64_t ld, float* out,
+                                int32_t accumulate, void* stream) {
+  TRIBE_REQUIRE(a && out, "tribe_colsum_fwd: null pointer");
+  TRIBE_REQUIRE(M > 0 && N > 0 && ld >= N, "tribe_colsum_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+    if (e != hipSuccess) { tribe_set_error("tribe_colsum_fwd: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  int64_t slices = (M + 127) / 128;
+  if (slices > 256) slices = 256;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)slices);
+  if (a_dtype == TRIBE_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)a, b, M, N, ld, out);
+  else if (a_dtype == TRIBE_BF16) hipLaunchKernelGGL(colsum_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)a, b, M, N, ld, out);
+  else TRIBE_REQUIRE(false, "tribe_colsum_fwd: dtype must be f32 or bf16");
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_scalenorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* g, float gain_scale, float eps,
+                                   int64_t rows, int64_t dim, const float* dres, const float* rs, float* dx, float* dg, void* stream) {
+  TRIBE_REQUIRE(x && dy && g && dx, "tribe_scalenorm_bwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && dim > 0, "tribe_scalenorm_bwd: bad shape");
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dy_dtype == TRIBE_F32)
+    hipLaunchKernelGGL(scalenorm_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (const float*)dy, g, gain_scale, eps, rows,
+                       dim, dres, rs, dx, dg);
+  else if (dy_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL(scalenorm_bwd_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, x, (const unsigned short*)dy, g,
+                       gain_scale, eps, rows, dim, dres, rs, dx, dg);
+  else
+    TRIBE_REQUIRE(false, "tribe_scalenorm_bwd: dy dtype must be f32 or bf16");
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_softmax_bwd(const uint16_t* P, const float* dP, int64_t rows, int64_t T, int64_t T_pad, int64_t ld_p, int64_t ld_dp,
+                                 float scale, uint16_t* dS, int64_t ld_ds, void* stream) {
+  TRIBE_REQUIRE(P && dP && dS, "tribe_softmax_bwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && T > 0 && T_pad >= T && ld_p >= T && ld_dp >= T && ld_ds >= T_pad, "tribe_softmax_bwd: bad shape");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, rows, T, T_pad, ld_p,
+                     ld_dp, scale, dS, ld_ds);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_softmax_fwd(const float* S, int64_t rows, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p, void* stream) {
+  TRIBE_REQUIRE(S && P, "tribe_softmax_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && T > 0 && T_pad >= T && ld_s >= T && ld_p >= T_pad, "tribe_softmax_fwd: bad shape");
+  return tribe_internal_softmax(S, rows, T, ld_s, P, T_pad, ld_p, (hipStream_t)stream);
+}
+
+extern "C" int tribe_mse_bwd(const float* pred, const float* truth, int64_t n, const float* gscale, float* dpred, void* stream) {
+  TRIBE_REQUIRE(pred && truth && gscale && dpred && n > 0, "tribe_mse_bwd: bad argument");
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, truth, n, gscale, dpred);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_adaptive_avg_pool_bwd(const float* dy, int64_t rows, int64_t T_in, int64_t T_out, float* dx, void* stream) {
+  TRIBE_REQUIRE(dy && dx && rows > 0 && T_in > 0 && T_out > 0, "tribe_adaptive_avg_pool_bwd: bad argument");
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(rows * T_in, 256)), dim3(256), 0, (hipStream_t)stream, dy, rows, T_in, T_out, dx);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_rowsum_scatter(const float* x, int64_t B, int64_t V, int64_t T, const int64_t* idx, float* out, void* stream) {
+  TRIBE_REQUIRE(x && idx && out && B > 0 && V > 0 && T > 0 && B < 65536, "tribe_rowsum_scatter: bad argument");
+  hipLaunchKernelGGL(rowsum_scatter_kernel, dim3((unsigned)((B * V + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, B, V, T, idx, out);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_scale_cols_fwd(const float* x, const float* rs, int64_t M, int64_t N, float* y, void* stream) {
+  TRIBE_REQUIRE(x && y && M > 0 && N > 0, "tribe_scale_cols_fwd: bad argument");
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(grid_for(M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, rs, M, N, y);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_cast_bf16_fwd(const float* x, int64_t n, uint16_t* y, void* stream) {
+  TRIBE_REQUIRE(x && y && n > 0 && n % 4 == 0, "tribe_cast_bf16_fwd: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const int64_t b1 = z / g.batch0, b0 = z - b1 * g.batch0;
   const int64_t b1g = g.gather1 ? g.gather1[b1] : b1;
   const unsigned short* A = (const unsigned short*)g.A + (g.gather_a ? b1g : b1) * g.sA1 + b0 * g.sA0;
-  const unsigned short* B = (const unsigned short*)g.B + b1 * g.sB1 + b0 * g.sB0;
+  const unsigned short* B = (const unsigned short*)g.B + (g.gather_b ? b1g : b1) * g.sB1 + b0 * g.sB0;
 
   // ---- staging: half-tile = the 128 tile rows read in one phase; each wave moves 2 slabs of 8 rows ----
   //   A half h: rows {wr'*128 + h*64 + 0..63, wr' = 0,1};   slab j of this wave: row0 = j*128 + h*64 + wave*8
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
   const int64_t b1 = z / g.batch0, b0 = z - b1 * g.batch0;
   const int64_t b1g = g.gather1 ? g.gather1[b1] : b1;
   const unsigned short* A = (const unsigned short*)g.A + (g.gather_a ? b1g : b1) * g.sA1 + b0 * g.sA0;
-  const unsigned short* B = (const unsigned short*)g.B + b1 * g.sB1 + b0 * g.sB0;
+  const unsigned short* B = (const unsigned short*)g.B + (g.gather_b ? b1g : b1) * g.sB1 + b0 * g.sB0;
 
   // ---- staging addresses: pass p covers tile rows [32p, 32p+32), wave w rows 8w.. of those ----
   const int srow = lane >> 3;
@@ -425,7 +425,9 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(d->bias_mode == TRIBE_BIAS_NONE || d->bias != nullptr, "tribe_gemm_bf16: bias_mode set without bias");
   TRIBE_REQUIRE(!d->rowadd || d->rowadd_period > 0, "tribe_gemm_bf16: rowadd needs a positive period");
   TRIBE_REQUIRE(!d->gadd || (d->gadd_index && d->gadd_div > 0), "tribe_gemm_bf16: gadd needs index and divisor");
-  TRIBE_REQUIRE(!(d->gather_a || d->gather_bias) || d->gather1, "tribe_gemm_bf16: gather flags set without gather1");
+  TRIBE_REQUIRE(!(d->gather_a || d->gather_bias || d->gather_b) || d->gather1, "tribe_gemm_bf16: gather flags set without gather1");
+  TRIBE_REQUIRE(d->act != TRIBE_ACT_GELU_BWD || d->aux, "tribe_gemm_bf16: GELU_BWD needs the saved pre-activation in aux");
+  TRIBE_REQUIRE(!d->aux || (d->ld_aux >= d->N && d->batch1 * d->batch0 == 1), "tribe_gemm_bf16: aux is supported for un-batched GEMMs");
   const int64_t nz = d->batch1 * d->batch0;
   // tile selection: 256^2 tiles when both extents fill them and the grid still covers the chip, else 128^2
   int use_big = (d->M >= 256 && d->N >= 256 && ((d->M + 255) / 256) * ((d->N + 255) / 256) * nz >= 96);

@@ -46,6 +46,13 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return v * (v < 0.f ? q : 1.0f - q);
 }
 
+// d/dv [v * Phi(v)] = Phi(v) + v * phi(v)
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
 __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
 }
@@ -84,6 +91,7 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const tribe_gemm_desc& g, int64_t
   if (g.res_scale) v = v && ((((uintptr_t)g.res_scale) & 15) == 0);
   if (g.rowadd) v = v && ((g.ld_rowadd & 3) == 0) && ((((uintptr_t)g.rowadd) & 15) == 0);
   if (g.gadd) v = v && ((g.ld_gadd & 3) == 0) && ((((uintptr_t)g.gadd) & 15) == 0);
+  if (g.aux) v = v && ((g.ld_aux & 3) == 0) && ((((uintptr_t)g.aux) & 7) == 0);
   c.vec = v;
   return c;
 }
@@ -139,8 +147,18 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
       return;
     }
     if (g.act == TRIBE_ACT_GELU) {
+      if (g.aux) {  // training forward: keep the pre-activation for the backward pass
+        u16x4_t pre;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pre[k] = f32_to_bf16(v[k]);
+        *(u16x4_t*)((unsigned short*)g.aux + c.c_off + m * g.ld_aux + n) = pre;
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = OUT_BF16 ? gelu_fast(v[k]) : gelu_erf(v[k]);
+    } else if (g.act == TRIBE_ACT_GELU_BWD) {
+      const u16x4_t pre = *(const u16x4_t*)((const unsigned short*)g.aux + c.c_off + m * g.ld_aux + n);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= gelu_grad(bf16_to_f32(pre[k]));
     } else if (g.act == TRIBE_ACT_SILU) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
@@ -190,8 +208,12 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
     if (n + k >= g.N) break;
     float x = v[k];
     if (g.bias_mode == TRIBE_BIAS_COL) x += c.bias[n + k];
-    if (g.act == TRIBE_ACT_GELU) x = OUT_BF16 ? gelu_fast(x) : gelu_erf(x);
-    else if (g.act == TRIBE_ACT_SILU) x = silu_f(x);
+    if (g.act == TRIBE_ACT_GELU) {
+      if (g.aux) ((unsigned short*)g.aux)[c.c_off + m * g.ld_aux + n + k] = f32_to_bf16(x);
+      x = OUT_BF16 ? gelu_fast(x) : gelu_erf(x);
+    } else if (g.act == TRIBE_ACT_GELU_BWD) {
+      x *= gelu_grad(bf16_to_f32(((const unsigned short*)g.aux)[c.c_off + m * g.ld_aux + n + k]));
+    } else if (g.act == TRIBE_ACT_SILU) x = silu_f(x);
     if (c.res) {
       const float r = c.res[m * g.ldres + n + k];
       x += g.res_scale ? r * g.res_scale[n + k] : r;

@@ -1,0 +1,416 @@
+"""Autograd functions of the training path: every forward AND backward is a HIP kernel launch (MFMA GEMMs for the
+dense gradients, streaming kernels for the rest); torch.autograd only orders the calls and owns the saved tensors.
+
+Conventions: activations that feed a GEMM are bf16 `[M, K]`; the residual stream and all parameter gradients are f32.
+For Y = X W^T (X [M, K], W [N, K]):
+    dX = dY W          -> NT GEMM with A = dY [M, N],   B = W^T [K, N]   (W^T packed once per weight version)
+    dW = dY^T X        -> NT GEMM with A = dY^T [N, M], B = X^T [K, M]   (transposes by tribe_transpose_bf16)
+    db = column sums of dY.
+Reference semantics followed: pl_module.py:126-128 (training_step = _run_step loss -> Lightning backward),
+model.py:113-174 (forward graph), x_transformers encoder (oracle/xt_encoder.py).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import typing as tp
+
+import torch
+
+from tribe_hip import _lib, ops
+from tribe_hip._lib import BF16, F32, GemmDesc, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, lda=None, ldb=None, ldc=None, M=None, N=None, K=None, alpha=1.0,
+          bias=None, act=_lib.ACT_NONE, aux=None, res=None, ldres=None, res_scale=None, batch1=1, batch0=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
+          gather1=None, gather_a=False, gather_b=False, a_off=0, b_off=0, c_off=0, role=0) -> None:
+    """Thin positional wrapper over tribe_gemm_bf16 (element offsets allow strided views without copies)."""
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, batch1, batch0
+    d.A, d.lda, d.sA1, d.sA0 = a.data_ptr() + 2 * a_off, lda, sA[0], sA[1]
+    d.B, d.ldb, d.sB1, d.sB0 = b.data_ptr() + 2 * b_off, ldb, sB[0], sB[1]
+    d.C, d.ldc, d.sC1, d.sC0 = out.data_ptr() + out.element_size() * c_off, ldc, sC[0], sC[1]
+    d.c_dtype, d.alpha, d.act, d.role = _DT[out.dtype], alpha, act, role
+    if bias is not None:
+        d.bias, d.bias_mode = bias.data_ptr(), _lib.BIAS_COL
+    if aux is not None:
+        d.aux, d.ld_aux = aux.data_ptr(), N
+    if res is not None:
+        d.res, d.ldres = res.data_ptr() + 4 * c_off, (ldres if ldres is not None else ldc)
+        d.sRes1, d.sRes0 = sC
+    if res_scale is not None:
+        d.res_scale = res_scale.data_ptr()
+    if gather1 is not None:
+        d.gather1, d.gather_a, d.gather_b = gather1.data_ptr(), int(gather_a), int(gather_b)
+    check(lib().tribe_gemm_bf16(C.byref(d), _s()), "tribe_gemm_bf16")
+
+
+def transpose_bf16(x: torch.Tensor, Z: int, R: int, Cc: int, s_z: int, s_r: int, off: int = 0) -> torch.Tensor:
+    """out[z, c, r] = x[z, r, c] as bf16 [Z, C, R_pad64] (x f32 or bf16, strided view given by element strides / offset)."""
+    R_pad = ops.round_up(R, 64)
+    out = torch.empty(Z, Cc, R_pad, dtype=torch.bfloat16, device=x.device)
+    check(lib().tribe_transpose_bf16(x.data_ptr() + x.element_size() * off, _DT[x.dtype], Z, R, Cc, s_z, s_r, out.data_ptr(), Cc * R_pad, R_pad,
+                                     _s()), "tribe_transpose_bf16")
+    return out
+
+
+def colsum(a: torch.Tensor, M: int, N: int, b: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    acc = out is not None
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+    check(lib().tribe_colsum_fwd(a.data_ptr(), _DT[a.dtype], ops._p(b), M, N, N, out.data_ptr(), int(acc), _s()), "tribe_colsum_fwd")
+    return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == torch.bfloat16:
+        return x.contiguous()
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().tribe_cast_bf16_fwd(x.data_ptr(), x.numel(), y.data_ptr(), _s()), "tribe_cast_bf16_fwd")
+    return y
+
+
+class _WeightPacks:
+    """bf16 W [N, K_pad] and W^T [K, N_pad] per (tensor object, version) of an f32 weight; entries die with the tensor
+    (temporaries such as the fused q|k|v weight are rebuilt every step, parameters only when they were updated)."""
+
+    def __init__(self) -> None:
+        self._c: dict[int, tuple[tp.Any, tuple, torch.Tensor, torch.Tensor]] = {}
+
+    def get(self, w: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        import weakref
+
+        key = id(w)
+        sig = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._c.get(key)
+        if hit is None or hit[0]() is not w or hit[1] != sig:
+            wd = w.detach().contiguous()
+            N, K = wd.shape
+            hit = (weakref.ref(w, lambda _r, k=key: self._c.pop(k, None)), sig, ops.pack_weight(wd), transpose_bf16(wd, 1, N, K, 0, K)[0])
+            self._c[key] = hit
+        return hit[2], hit[3]
+
+
+PACKS = _WeightPacks()
+
+
+# ------------------------------------------------------------------------------------------------------------
+class Linear(torch.autograd.Function):
+    """y = x W^T + b (+ res * res_scale).  x bf16 [M, K]; W f32 [N, K]; y bf16 or f32 [M, N]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, res_scale, out_f32: bool):
+        M, K = x.shape
+        N = w.shape[0]
+        wp, _ = PACKS.get(w)
+        Kp = wp.shape[1]
+        if Kp != K:
+            raise ValueError(f"Linear: activation width {K} must equal the packed K {Kp} (pad activations to 64)")
+        y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        _gemm(x, wp, y, lda=K, ldb=Kp, ldc=N, M=M, N=N, K=K, bias=b, res=res, res_scale=res_scale)
+        ctx.save_for_backward(x, w, res, res_scale)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, res, res_scale = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        dy = dy.contiguous()
+        dres = drs = None
+        if res is not None:
+            dres = torch.empty_like(res)
+            check(lib().tribe_scale_cols_fwd(dy.data_ptr(), ops._p(res_scale), M, N, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
+            if res_scale is not None:
+                drs = colsum(dy, M, N, b=res)
+        _, wt = PACKS.get(w)  # [K, N_pad64]
+        Np = wt.shape[1]
+        dpre = cast_bf16(dy)
+        if Np != N:
+            dpre = torch.nn.functional.pad(dpre, (0, Np - N))  # zero K-padding for the dgrad GEMM (N % 64 != 0 only)
+        dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+        _gemm(dpre, wt, dx, lda=Np, ldb=Np, ldc=K, M=M, N=K, K=Np)
+        # dW[n, k] = sum_m dpre[m, n] x[m, k]
+        dpre_t = transpose_bf16(dpre, 1, M, N, 0, Np)[0]  # [N, M_pad]
+        x_t = transpose_bf16(x, 1, M, K, 0, K)[0]         # [K, M_pad]
+        Mp = dpre_t.shape[1]
+        dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        _gemm(dpre_t, x_t, dw, lda=Mp, ldb=Mp, ldc=K, M=N, N=K, K=Mp)
+        dw = dw[:, : w.shape[1]] if w.shape[1] != K else dw
+        db = colsum(dpre, M, N) if ctx.has_b else None
+        if Np != N and db is not None:
+            db = db[:N]
+        return dx, dw, db, dres, drs, None
+
+
+class FeedForward(torch.autograd.Function):
+    """out = gelu(x W1^T + b1) W2^T + b2 + res * res_scale  (x_transformers FeedForward + scaled residual).
+    x bf16 [M, D]; res f32 [M, D] (the block input); out f32 [M, D]."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res, res_scale):
+        M, D = x.shape
+        Fh = w1.shape[0]
+        w1p, _ = PACKS.get(w1)
+        w2p, _ = PACKS.get(w2)
+        pre = torch.empty(M, Fh, dtype=torch.bfloat16, device=x.device)
+        h = torch.empty(M, Fh, dtype=torch.bfloat16, device=x.device)
+        _gemm(x, w1p, h, lda=D, ldb=D, ldc=Fh, M=M, N=Fh, K=D, bias=b1, act=_lib.ACT_GELU, aux=pre, role=6)
+        out = torch.empty(M, D, dtype=torch.float32, device=x.device)
+        _gemm(h, w2p, out, lda=Fh, ldb=Fh, ldc=D, M=M, N=D, K=Fh, bias=b2, res=res, res_scale=res_scale, role=7)
+        ctx.save_for_backward(x, w1, w2, pre, h, res, res_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, w2, pre, h, res, res_scale = ctx.saved_tensors
+        M, D = x.shape
+        Fh = w1.shape[0]
+        dout = dout.contiguous()
+        dres = torch.empty_like(res)
+        check(lib().tribe_scale_cols_fwd(dout.data_ptr(), ops._p(res_scale), M, D, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
+        drs = colsum(dout, M, D, b=res) if res_scale is not None else None
+        db2 = colsum(dout, M, D)
+        dob = cast_bf16(dout)                                   # [M, D]
+        _, w2t = PACKS.get(w2)                                  # [Fh, D]
+        dpre = torch.empty(M, Fh, dtype=torch.bfloat16, device=x.device)
+        _gemm(dob, w2t, dpre, lda=D, ldb=D, ldc=Fh, M=M, N=Fh, K=D, act=_lib.ACT_GELU_BWD, aux=pre)   # dh * gelu'(pre)
+        dob_t = transpose_bf16(dob, 1, M, D, 0, D)[0]           # [D, Mp]
+        h_t = transpose_bf16(h, 1, M, Fh, 0, Fh)[0]             # [Fh, Mp]
+        Mp = dob_t.shape[1]
+        dw2 = torch.empty(D, Fh, dtype=torch.float32, device=x.device)
+        _gemm(dob_t, h_t, dw2, lda=Mp, ldb=Mp, ldc=Fh, M=D, N=Fh, K=Mp)
+        db1 = colsum(dpre, M, Fh)
+        _, w1t = PACKS.get(w1)                                  # [D, Fh]
+        dx = torch.empty(M, D, dtype=torch.float32, device=x.device)
+        _gemm(dpre, w1t, dx, lda=Fh, ldb=Fh, ldc=D, M=M, N=D, K=Fh)
+        dpre_t = transpose_bf16(dpre, 1, M, Fh, 0, Fh)[0]       # [Fh, Mp]
+        x_t = transpose_bf16(x, 1, M, D, 0, D)[0]               # [D, Mp]
+        dw1 = torch.empty(Fh, D, dtype=torch.float32, device=x.device)
+        _gemm(dpre_t, x_t, dw1, lda=Mp, ldb=Mp, ldc=D, M=Fh, N=D, K=Mp)
+        return dx, dw1, db1, dw2, db2, dres, drs
+
+
+class ScaleNorm(torch.autograd.Function):
+    """y = x / max(||x||, eps) * gain_scale * g  (bf16 out; x f32 [M, D])."""
+
+    @staticmethod
+    def forward(ctx, x, g, gain_scale: float, eps: float, out_f32: bool = False):
+        y = ops.scalenorm(x, g, gain_scale, eps, torch.float32 if out_f32 else torch.bfloat16)
+        ctx.save_for_backward(x, g)
+        ctx.gs, ctx.eps = gain_scale, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, D = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.zeros(1, dtype=torch.float32, device=x.device)
+        check(lib().tribe_scalenorm_bwd(x.data_ptr(), dy.data_ptr(), _DT[dy.dtype], g.data_ptr(), ctx.gs, ctx.eps, M, D, None, None,
+                                        dx.data_ptr(), dg.data_ptr(), _s()), "tribe_scalenorm_bwd")
+        return dx, dg, None, None, None
+
+
+class Rotary(torch.autograd.Function):
+    """In-place partial rotary on the q and k heads of a fused qkv buffer (returns the same storage)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, T: int, heads: int, dim_head: int, rot_dim: int, interleaved: bool):
+        ctx.mark_dirty(qkv)
+        ops.rotary_(qkv, T, heads, dim_head, rot_dim, cos, sin, interleaved)
+        ctx.save_for_backward(cos, sin)
+        ctx.meta = (T, heads, dim_head, rot_dim, interleaved)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        cos, sin = ctx.saved_tensors
+        T, heads, dim_head, rot_dim, interleaved = ctx.meta
+        d = dqkv.contiguous().clone() if not dqkv.is_contiguous() else dqkv.clone()
+        ops.rotary_(d, T, heads, dim_head, rot_dim, cos, (-sin).contiguous(), interleaved)  # rotation by -theta = transpose
+        return d, None, None, None, None, None, None, None
+
+
+class Attention(torch.autograd.Function):
+    """softmax(q k^T * scale) v per (batch, head) on a fused bf16 qkv [B*T, 3*inner]; forward = fused flash kernel,
+    backward = materialised (S, P recomputed per batch chunk; five MFMA GEMM products per head)."""
+
+    CHUNK_BYTES = 256 << 20
+
+    @staticmethod
+    def forward(ctx, qkv, B: int, T: int, heads: int, dim_head: int, scale: float):
+        out = ops.attention(qkv, B, T, heads, dim_head, scale)
+        ctx.save_for_backward(qkv)
+        ctx.meta = (B, T, heads, dim_head, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        B, T, h, d, scale = ctx.meta
+        inner, ld = h * d, 3 * h * d
+        dev = qkv.device
+        dout = cast_bf16(dout)
+        dqkv = torch.empty_like(qkv)
+        Tp = ops.round_up(T, 64)
+        chunk = max(1, min(B, Attention.CHUNK_BYTES // (h * T * Tp * 4)))
+        S = torch.empty(chunk * h, T, Tp, dtype=torch.float32, device=dev)
+        P = torch.empty(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
+        dP = torch.empty(chunk * h, T, Tp, dtype=torch.float32, device=dev)
+        dS = torch.empty(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
+        st = _s()
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            Z = nb * h
+            row0 = b0 * T
+            q_off, k_off, v_off = row0 * ld, row0 * ld + inner, row0 * ld + 2 * inner
+            # S = scale * Q K^T ;  P = softmax(S)
+            _gemm(qkv, qkv, S, lda=ld, ldb=ld, ldc=Tp, M=T, N=T, K=d, alpha=scale, batch1=nb, batch0=h, sA=(T * ld, d), sB=(T * ld, d),
+                  sC=(h * T * Tp, T * Tp), a_off=q_off, b_off=k_off)
+            check(lib().tribe_softmax_fwd(S.data_ptr(), Z * T, T, Tp, P.data_ptr(), Tp, Tp, st), "tribe_softmax_fwd")
+            # dP = dO V^T
+            _gemm(dout, qkv, dP, lda=inner, ldb=ld, ldc=Tp, M=T, N=T, K=d, batch1=nb, batch0=h, sA=(T * inner, d), sB=(T * ld, d),
+                  sC=(h * T * Tp, T * Tp), a_off=row0 * inner, b_off=v_off)
+            # dS = P * (dP - rowsum(P dP)) * scale
+            check(lib().tribe_softmax_bwd(P.data_ptr(), dP.data_ptr(), Z * T, T, Tp, Tp, Tp, scale, dS.data_ptr(), Tp, st), "tribe_softmax_bwd")
+            # transposed operands:  per (b, h) views of q / k / dO [T, d] -> [d, Tp];  P, dS [T, T] -> [T, Tp]
+            qT = _head_transpose(qkv, nb, h, T, d, ld, q_off)
+            kT = _head_transpose(qkv, nb, h, T, d, ld, k_off)
+            doT = _head_transpose(dout, nb, h, T, d, inner, row0 * inner)
+            PT = transpose_bf16(P, Z, T, T, T * Tp, Tp)
+            dST = transpose_bf16(dS, Z, T, T, T * Tp, Tp)
+            # dV[key, :] = sum_q P[q, key] dO[q, :]
+            _gemm(PT, doT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
+                  sC=(T * ld, d), c_off=v_off)
+            # dQ[q, :] = sum_key dS[q, key] K[key, :]
+            _gemm(dS, kT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
+                  sC=(T * ld, d), c_off=q_off)
+            # dK[key, :] = sum_q dS[q, key] Q[q, :]
+            _gemm(dST, qT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
+                  sC=(T * ld, d), c_off=k_off)
+        return dqkv, None, None, None, None, None
+
+
+def _head_transpose(x: torch.Tensor, nb: int, h: int, T: int, d: int, ld: int, off: int) -> torch.Tensor:
+    """[nb, T, (h, d)] strided view -> bf16 [nb*h, d, T_pad] (one launch per batch element: heads are the z axis)."""
+    Tp = ops.round_up(T, 64)
+    out = torch.empty(nb * h, d, Tp, dtype=torch.bfloat16, device=x.device)
+    for b in range(nb):
+        check(lib().tribe_transpose_bf16(x.data_ptr() + x.element_size() * (off + b * T * ld), _DT[x.dtype], h, T, d, d, ld,
+                                         out.data_ptr() + 2 * b * h * d * Tp, d * Tp, Tp, _s()), "tribe_transpose_bf16")
+    return out
+
+
+class VoxelHead(torch.autograd.Function):
+    """SubjectLayers: y[b, v, t] = sum_c x[b, t, c] W[s_b, c, v] + bias[s_b, v].  x bf16 [B, T, C]; y f32 [B, V, T]."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, subjects):
+        S, Cc, V = w.shape
+        wp = ops.pack_subject_weights(w.detach().contiguous())
+        y = ops.voxel_head(x, wp, None if bias is None else bias.detach().contiguous(), subjects, V)
+        ctx.save_for_backward(x, w, subjects)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, subjects = ctx.saved_tensors
+        B, T, Cp = x.shape
+        S, Cc, V = w.shape
+        dy = dy.contiguous()
+        dev = x.device
+        Vp, Tp = ops.round_up(V, 64), ops.round_up(T, 64)
+        # dx[b, t, c] = sum_v dy[b, v, t] W[s_b, c, v]:  A = dy_b^T [T, Vp],  B = W[s_b] [C, Vp]
+        dyT = ops.pack_features(dy, layer_mean=False, K_pad=Vp).view(B, T, Vp)            # "b v t -> b t v" + cast
+        wv = ops.pack_weight(w.detach().reshape(S * Cc, V).contiguous(), cols_pad=Vp)     # [S*C, Vp]
+        dx = torch.empty(B, T, Cp, dtype=torch.float32, device=dev)
+        if Cp != Cc:
+            dx.zero_()
+        _gemm(dyT, wv, dx, lda=Vp, ldb=Vp, ldc=Cp, M=T, N=Cc, K=Vp, batch1=B, sA=(T * Vp, 0), sB=(Cc * Vp, 0), sC=(T * Cp, 0),
+              gather1=subjects, gather_b=True)
+        # dW[s, c, v] += sum_t x[b, t, c] dy[b, v, t]  for every sample b of subject s:  A = x_b^T [C, Tp], B = dy_b [V, Tp]
+        xT = transpose_bf16(x, B, T, Cc, T * Cp, Cp)                                        # [B, C, Tp]
+        dyb = ops.pack_weight(dy.reshape(B * V, T), cols_pad=Tp)                            # [B*V, Tp] bf16
+        dw = torch.zeros(S, Cc, V, dtype=torch.float32, device=dev)
+        for b, s in enumerate(subjects.tolist()):
+            _gemm(xT, dyb, dw, lda=Tp, ldb=Tp, ldc=V, M=Cc, N=V, K=Tp, a_off=b * Cc * Tp, b_off=b * V * Tp, c_off=s * Cc * V, res=dw,
+                  ldres=V)
+        db = None
+        if ctx.has_bias:
+            db = torch.zeros(S, V, dtype=torch.float32, device=dev)
+            check(lib().tribe_rowsum_scatter(dy.data_ptr(), B, V, T, subjects.data_ptr(), db.data_ptr(), _s()), "tribe_rowsum_scatter")
+        return dx, dw, db, None
+
+
+class AdaptivePool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t_out: int):
+        ctx.t_in, ctx.t_out = x.shape[-1], t_out
+        return ops.adaptive_avg_pool(x.contiguous(), t_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        rows = dy.numel() // ctx.t_out
+        dx = torch.empty(*dy.shape[:-1], ctx.t_in, dtype=torch.float32, device=dy.device)
+        check(lib().tribe_adaptive_avg_pool_bwd(dy.data_ptr(), rows, ctx.t_in, ctx.t_out, dx.data_ptr(), _s()), "tribe_adaptive_avg_pool_bwd")
+        return dx, None
+
+
+class MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, true):
+        pred, true = pred.contiguous(), true.contiguous()
+        ctx.save_for_backward(pred, true)
+        return ops.mse(pred, true)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, true = ctx.saved_tensors
+        dp = torch.empty_like(pred)
+        g = g.reshape(1).to(torch.float32).contiguous()
+        check(lib().tribe_mse_bwd(pred.data_ptr(), true.data_ptr(), pred.numel(), g.data_ptr(), dp.data_ptr(), _s()), "tribe_mse_bwd")
+        return dp, None
+
+
+class ProjectorFuse(torch.autograd.Function):
+    """One modality's projector writing its column slice of the fused stream (+ positional / subject embeddings are
+    added by EmbedAdd).  feat bf16 [M, Kp]; W f32 [N, K]; out slice f32 [M, N] (a fresh tensor; concat is done by cat)."""
+
+    @staticmethod
+    def forward(ctx, feat, w, b):
+        M, Kp = feat.shape
+        N = w.shape[0]
+        wp, _ = PACKS.get(w)
+        y = torch.empty(M, N, dtype=torch.float32, device=feat.device)
+        _gemm(feat, wp, y, lda=Kp, ldb=Kp, ldc=N, M=M, N=N, K=Kp, bias=b, role=1)
+        ctx.save_for_backward(feat, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feat, w = ctx.saved_tensors
+        M, Kp = feat.shape
+        N, K = w.shape
+        dy = dy.contiguous()
+        dyb = cast_bf16(dy)
+        dy_t = transpose_bf16(dyb, 1, M, N, 0, N)[0]
+        f_t = transpose_bf16(feat, 1, M, Kp, 0, Kp)[0]
+        Mp = dy_t.shape[1]
+        dw = torch.empty(N, Kp, dtype=torch.float32, device=feat.device)
+        _gemm(dy_t, f_t, dw, lda=Mp, ldb=Mp, ldc=Kp, M=N, N=Kp, K=Mp)
+        return None, dw[:, :K].contiguous() if Kp != K else dw, colsum(dy, M, N)
+
+
+_ = tp

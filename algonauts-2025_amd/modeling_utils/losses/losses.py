@@ -7,7 +7,7 @@ counterpart of `torch.nn.MSELoss()` selected by defaults.py:125.
 Both accept what the reference passes -- two [N, V] matrices, columns = voxels -- and, as the
 fast path used by BrainModule, the un-flattened [B, V, T'] pair via `forward_bvt` (the '(b t) d'
 flatten of pl_module.py:54-55 is a pure re-indexing of the same sums and is never materialised).
-Forward only in this round (no autograd graph is recorded).
+`MSELoss` is differentiable (HIP backward kernel); `PearsonLoss` is forward only so far.
 """
 
 from __future__ import annotations
@@ -54,6 +54,10 @@ class MSELoss(nn.Module):
     def forward(self, pred: torch.Tensor, true: torch.Tensor) -> torch.Tensor:
         if pred.shape != true.shape:
             raise ValueError(f"MSELoss: shape mismatch {tuple(pred.shape)} vs {tuple(true.shape)}")
+        if torch.is_grad_enabled() and pred.requires_grad:
+            from ..autograd import MSE
+
+            return MSE.apply(pred.float(), true.float())
         return ops.mse(pred.float().contiguous(), true.float().contiguous())
 
     forward_bvt = forward

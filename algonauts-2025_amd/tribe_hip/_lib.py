@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libtribe_hip.so"
 
 F32, BF16, F64 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU, ACT_GLU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU, ACT_GLU, ACT_GELU_BWD = 0, 1, 2, 3, 4, 5
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head"]
 
@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("res_scale", vp),
         ("rowadd", vp), ("ld_rowadd", i64), ("rowadd_period", i64),
         ("gadd", vp), ("gadd_index", vp), ("gadd_div", i64), ("ld_gadd", i64),
+        ("aux", vp), ("ld_aux", i64), ("gather_b", i32),
         ("role", i32), ("tile_hint", i32),
     ]
 
@@ -167,6 +168,16 @@ SIGNATURES = {
     "tribe_gather_rows_fwd": (C.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
     "tribe_w2vbert_workspace_bytes": (sz, [C.POINTER(W2vBertDesc)]),
     "tribe_w2vbert_fwd": (C.c_int, [C.POINTER(W2vBertDesc), vp, vp, sz, vp]),
+    "tribe_transpose_bf16": (C.c_int, [vp, i32, i64, i64, i64, i64, i64, vp, i64, i64, vp]),
+    "tribe_colsum_fwd": (C.c_int, [vp, i32, vp, i64, i64, i64, vp, i32, vp]),
+    "tribe_scalenorm_bwd": (C.c_int, [vp, vp, i32, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp]),
+    "tribe_softmax_bwd": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, f32, vp, i64, vp]),
+    "tribe_softmax_fwd": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),
+    "tribe_mse_bwd": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+    "tribe_adaptive_avg_pool_bwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
+    "tribe_rowsum_scatter": (C.c_int, [vp, i64, i64, i64, vp, vp, vp]),
+    "tribe_scale_cols_fwd": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "tribe_cast_bf16_fwd": (C.c_int, [vp, i64, vp, vp]),
     "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
     "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),

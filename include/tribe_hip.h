@@ -38,7 +38,8 @@ enum tribe_act {
   TRIBE_ACT_GELU = 1,   /* exact (erf) GELU */
   TRIBE_ACT_SWIGLU = 2, /* columns come in (gate, up) pairs: out[:, j] = silu(v[:, 2j]) * v[:, 2j+1]; C has N/2 columns */
   TRIBE_ACT_SILU = 3,
-  TRIBE_ACT_GLU = 4     /* (a, b) column pairs: out[:, j] = v[:, 2j] * sigmoid(v[:, 2j+1]); C has N/2 columns (nn.GLU) */
+  TRIBE_ACT_GLU = 4,    /* (a, b) column pairs: out[:, j] = v[:, 2j] * sigmoid(v[:, 2j+1]); C has N/2 columns (nn.GLU) */
+  TRIBE_ACT_GELU_BWD = 5 /* backward of GELU: out = v * gelu'(aux[m][n]), aux = saved pre-activation (bf16) */
 };
 enum tribe_bias_mode { TRIBE_BIAS_NONE = 0, TRIBE_BIAS_COL = 1, TRIBE_BIAS_ROW = 2 };
 /* which operator of the path a GEMM launch serves: selects the kernel SYMBOL (per-operator rows in
@@ -77,6 +78,10 @@ typedef struct tribe_gemm_desc {
   const float* res_scale;  /* f32 [N] or NULL (= 1) */
   const float* rowadd; int64_t ld_rowadd, rowadd_period; /* + rowadd[(m % period)][n] */
   const float* gadd; const int64_t* gadd_index; int64_t gadd_div, ld_gadd; /* + gadd[gadd_index[m / div]][n] */
+  /* aux bf16 [M, N] (ld_aux): with act == GELU the PRE-activation is also stored there (training forward);
+   * with act == GELU_BWD it is read.  NULL = unused. */
+  void* aux; int64_t ld_aux;
+  int32_t gather_b;        /* gather1 also replaces b1 for the B operand */
   int32_t role;            /* enum tribe_gemm_role */
   int32_t tile_hint;       /* 0 = automatic, 1 = force 128x128 tiles, 2 = force 256x256 tiles (tests / tuning) */
 } tribe_gemm_desc;
@@ -342,6 +347,39 @@ int tribe_pearson_loss_fwd(const float* pred, const float* truth, int64_t B, int
                            int64_t sb, int64_t sv, int64_t st,
                            int32_t reduction_sum, float* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t tribe_pearson_loss_workspace_bytes(int64_t V);
+
+/* ------------------------------------------------------------------------- *
+ * Backward building blocks (pl_module.training_step: loss.backward() of the path).
+ * Composition lives in the host-side autograd functions (modeling_utils/autograd.py).
+ * ------------------------------------------------------------------------- */
+/* out[z, c, r] = in[z, r, c] as bf16, rows of `out` zero-padded to R_pad; `in` is f32 or bf16 with element strides
+ * (s_z, s_r, 1).  Used for the transposed operands of the weight-gradient GEMMs and of attention backward. */
+int tribe_transpose_bf16(const void* in, int32_t in_dtype, int64_t Z, int64_t R, int64_t C, int64_t s_z, int64_t s_r,
+                         uint16_t* out, int64_t so_z, int64_t R_pad, void* stream);
+/* out[n] (+)= sum_m a[m, n] * (b ? b[m, n] : 1)   (bias, residual_scale and positional-embedding gradients) */
+int tribe_colsum_fwd(const void* a, int32_t a_dtype, const float* b, int64_t M, int64_t N, int64_t ld, float* out,
+                     int32_t accumulate, void* stream);
+/* ScaleNorm backward: y = x * s / max(||x||, eps), s = gain_scale * g.
+ *   dx[m, :] = (dres ? dres[m, :] * (rs ? rs : 1) : 0) + s / ||x|| * (dy - xhat * <xhat, dy>);   dg += gain_scale * sum_m <xhat, dy>
+ * dy bf16 or f32 [M, dim]; dres / dx f32 (may alias). */
+int tribe_scalenorm_bwd(const float* x, const void* dy, int32_t dy_dtype, const float* g, float gain_scale, float eps,
+                        int64_t rows, int64_t dim, const float* dres, const float* rs, float* dx, float* dg, void* stream);
+/* dS = P * (dP - rowsum(P * dP)) * scale   (softmax backward; P bf16, dP f32, dS bf16; row strides ld_p, ld_dp, ld_ds;
+ * columns >= T of dS are zero-filled up to T_pad) */
+int tribe_softmax_bwd(const uint16_t* P, const float* dP, int64_t rows, int64_t T, int64_t T_pad, int64_t ld_p, int64_t ld_dp,
+                      float scale, uint16_t* dS, int64_t ld_ds, void* stream);
+/* row softmax used by the materialised attention of the training path: S f32 [rows, T] -> P bf16 [rows, T_pad] */
+int tribe_softmax_fwd(const float* S, int64_t rows, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p, void* stream);
+/* d pred = gscale[0] * 2 / n * (pred - true)   (nn.MSELoss backward) */
+int tribe_mse_bwd(const float* pred, const float* truth, int64_t n, const float* gscale, float* dpred, void* stream);
+/* adaptive average pool backward: dx[r, t] = sum_{i: t in window i} dy[r, i] / |window i| */
+int tribe_adaptive_avg_pool_bwd(const float* dy, int64_t rows, int64_t T_in, int64_t T_out, float* dx, void* stream);
+/* out[idx[b], v] += sum_t x[b, v, t]   (SubjectLayers bias gradient) */
+int tribe_rowsum_scatter(const float* x, int64_t B, int64_t V, int64_t T, const int64_t* idx, float* out, void* stream);
+/* y = x * rs (columns), f32 [M, N]; rs NULL = copy */
+int tribe_scale_cols_fwd(const float* x, const float* rs, int64_t M, int64_t N, float* y, void* stream);
+/* f32 -> bf16 elementwise (gradient casts) */
+int tribe_cast_bf16_fwd(const float* x, int64_t n, uint16_t* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ ROOT = Path(__file__).resolve().parent.parent
 CS = ROOT / "algonauts-2025_amd" / "csrc"
 out = ROOT / "gpurun_out" / "libtribe_hip_stamps.so"
 out.parent.mkdir(exist_ok=True)
-srcs = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "encoder.hip", "extractors.hip", "abi.cpp"]
+srcs = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "encoder.hip", "extractors.hip", "backward.hip", "abi.cpp"]
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-DTRIBE_GEMM_STAMPS", "-shared",
                 *[str(CS / s) for s in srcs], "-o", str(out)], check=True)
 os.environ["TRIBE_HIP_LIB"] = str(out)

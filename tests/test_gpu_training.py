@@ -1,0 +1,118 @@
+"""GPU: the backward pass (pl_module.training_step -> loss.backward()) against the CPU oracle's autograd.
+Every forward and backward op of the training path is a HIP kernel; torch.autograd only orders them.
+Tolerance: bf16 GEMM operands (activations, weights AND incoming gradients are rounded to bf16 before each MFMA
+product, f32 accumulation) vs an fp32 CPU graph -> per-tensor relative L2 error of a few 1e-2 at most."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tribe_ref  # noqa: E402
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_autograd_blocks_vs_torch():
+    """Each autograd function alone vs a plain torch fp32 graph fed the same bf16-rounded inputs."""
+    from modeling_utils import autograd as ag
+
+    g = torch.Generator().manual_seed(0)
+    dev = "cuda"
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    # --- Linear with scaled residual
+    M, K, N = 200, 128, 192
+    x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K**0.5); b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g); rs = torch.rand(N, generator=g) + 0.5; dy = bf(torch.randn(M, N, generator=g))
+    wt, bt, rt, rst = (t.clone().requires_grad_() for t in (w, b, res, rs)); xt = x.clone().requires_grad_()
+    (xt @ wt.t() + bt + rt * rst).backward(dy)
+    xg = x.to(dev).bfloat16().requires_grad_(); wg, bg, rg, rsg = (t.to(dev).requires_grad_() for t in (w, b, res, rs))
+    y = ag.Linear.apply(xg, wg, bg, rg, rsg, True)
+    y.backward(dy.to(dev))
+    for name, got, want in (("dx", xg.grad.float(), xt.grad), ("dw", wg.grad, wt.grad), ("db", bg.grad, bt.grad), ("dres", rg.grad, rt.grad),
+                            ("drs", rsg.grad, rst.grad)):
+        assert _rel(got.cpu(), want) < 2e-2, name
+    # --- FeedForward
+    D, Fh = 128, 256
+    x = bf(torch.randn(M, D, generator=g)); w1 = bf(torch.randn(Fh, D, generator=g) / D**0.5); b1 = torch.randn(Fh, generator=g) * 0.1
+    w2 = bf(torch.randn(D, Fh, generator=g) / Fh**0.5); b2 = torch.randn(D, generator=g) * 0.1
+    res = torch.randn(M, D, generator=g); rs = torch.rand(D, generator=g) + 0.5; dy = bf(torch.randn(M, D, generator=g))
+    ts = [t.clone().requires_grad_() for t in (x, w1, b1, w2, b2, res, rs)]
+    (torch.nn.functional.gelu(ts[0] @ ts[1].t() + ts[2]) @ ts[3].t() + ts[4] + ts[5] * ts[6]).backward(dy)
+    gs = [x.to(dev).bfloat16().requires_grad_()] + [t.to(dev).requires_grad_() for t in (w1, b1, w2, b2, res, rs)]
+    ag.FeedForward.apply(*gs).backward(dy.to(dev))
+    for name, got, want in zip(("dx", "dw1", "db1", "dw2", "db2", "dres", "drs"), gs, ts):
+        assert _rel(got.grad.float().cpu(), want.grad) < 3e-2, name
+    # --- ScaleNorm
+    x = torch.randn(50, 256, generator=g); gpar = torch.tensor([1.3]); dy = torch.randn(50, 256, generator=g)
+    xt, gt = x.clone().requires_grad_(), gpar.clone().requires_grad_()
+    (xt / xt.norm(dim=-1, keepdim=True).clamp(min=1e-12) * 16.0 * gt).backward(dy)
+    xg, gg = x.to(dev).requires_grad_(), gpar.to(dev).requires_grad_()
+    ag.ScaleNorm.apply(xg, gg, 16.0, 1e-12, True).backward(dy.to(dev))
+    assert _rel(xg.grad.cpu(), xt.grad) < 1e-4 and _rel(gg.grad.cpu(), gt.grad) < 1e-4
+    # --- Attention (+ rotary): grads wrt the fused qkv buffer
+    B, T, h, d = 2, 70, 2, 64
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g)); dout = bf(torch.randn(B * T, h * d, generator=g))
+    qt = qkv.clone().requires_grad_()
+    q, k, v = (t.transpose(1, 2) for t in qt.view(B, T, 3, h, d).unbind(2))
+    att = (torch.einsum("bhid,bhjd->bhij", q, k) * d**-0.5).softmax(-1)
+    torch.einsum("bhij,bhjd->bhid", att, v).transpose(1, 2).reshape(B * T, h * d).backward(dout)
+    qg = qkv.to(dev).bfloat16().requires_grad_()
+    ag.Attention.apply(qg, B, T, h, d, d**-0.5).backward(dout.to(dev).bfloat16())
+    assert _rel(qg.grad.float().cpu(), qt.grad) < 3e-2
+    # --- adaptive pool and MSE
+    x = torch.randn(3, 5, 14, generator=g); xt = x.clone().requires_grad_()
+    dy = torch.randn(3, 5, 5, generator=g)
+    torch.nn.functional.adaptive_avg_pool1d(xt, 5).backward(dy)
+    xg = x.to(dev).requires_grad_()
+    ag.AdaptivePool.apply(xg, 5).backward(dy.to(dev))
+    torch.testing.assert_close(xg.grad.cpu(), xt.grad, rtol=1e-5, atol=1e-6)
+    p, t = torch.randn(4, 6, 9, generator=g), torch.randn(4, 6, 9, generator=g)
+    pt = p.clone().requires_grad_(); (((pt - t) ** 2).mean() * 3.0).backward()
+    pg = p.to(dev).requires_grad_(); (ag.MSE.apply(pg, t.to(dev)) * 3.0).backward()
+    torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("cfg_kw", [{}, {"layer_aggregation": "mean", "subject_embedding": True}])
+def test_training_step_gradients_vs_oracle(cfg_kw):
+    """BrainModule.training_step + loss.backward(): loss and every parameter gradient vs the fp32 CPU oracle graph."""
+    from algonauts2025.model import FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from data_utils.dataloader import SegmentData
+    from modeling_utils.losses import TorchLossConfig
+
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    V, Tout, S, B, T = 50, 10, 3, 4, 31
+    dims = tribe_ref.EncoderDims(hidden=768, depth=2, heads=4)
+    ref = tribe_ref.FmriEncoderRef(fdims, V, Tout, S, layer_aggregation=cfg_kw.get("layer_aggregation", "cat"),
+                                   subject_embedding=cfg_kw.get("subject_embedding", False), dims=dims).train()
+    with torch.no_grad():
+        tribe_ref.fill_params_(ref, seed=2)
+    model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=2, heads=4, **cfg_kw).build(fdims, V, Tout)
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda().train()
+    data = tribe_ref.synthetic_batch(B, T, fdims, S, seed=4)
+    fmri = torch.randn(B, V, Tout, generator=torch.Generator().manual_seed(9))
+    # oracle
+    loss_ref, *_ = tribe_ref.run_step(ref(data), fmri, data["subject_id"])
+    loss_ref.backward()
+    # HIP
+    bm = BrainModule(model, TorchLossConfig(name="MSELoss").build(), None, {})
+    batch = SegmentData(data={**{k: v.cuda() for k, v in data.items()}, "fmri": fmri.cuda()}, segments=[None] * B)
+    loss = bm.training_step(batch, 0)
+    assert loss.requires_grad and abs(float(loss) - float(loss_ref)) < 2e-3 * max(1.0, float(loss_ref))
+    loss.backward()
+    ref_grads = dict(ref.named_parameters())
+    worst = {}
+    for name, p in model.named_parameters():
+        want = ref_grads[name].grad
+        if want is None:
+            continue
+        assert p.grad is not None, f"no gradient for {name}"
+        worst[name] = _rel(p.grad.cpu(), want)
+    bad = {k: v for k, v in worst.items() if v > 6e-2}
+    assert not bad, f"gradient mismatch: {bad}"
+    print("max grad rel err", max(worst.values()), "over", len(worst), "tensors")
