@@ -182,8 +182,9 @@ def test_run_step_and_metrics_vs_oracle():
 
     r_cmp = compute_multidim_pearson(bm, _Loader([_cuda_batch(d) for d in batches]))
     np.testing.assert_allclose(r_cmp, r_gpu, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        bm.training_step(_cuda_batch(batches[0]), 0)
+    # training_step returns the loss (pl_module.py:126-128); gradient parity is in tests/test_gpu_training.py
+    want_loss, *_ = tribe_ref.run_step(ref_preds[0], trues[0], batches[0]["subject_id"])
+    assert abs(float(bm.training_step(_cuda_batch(batches[0]), 0)) - float(want_loss)) < 5e-3 * max(1.0, float(want_loss))
 
 
 def test_full_size_pearson_parity():
