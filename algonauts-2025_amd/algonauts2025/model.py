@@ -177,7 +177,8 @@ class FmriEncoder(nn.Module):
         # Lightning runs training_step in train mode with grad enabled; evaluation (.eval()) keeps the fused fast path
         return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
-    def _forward_autograd(self, data: dict[str, torch.Tensor], pool_outputs: bool) -> torch.Tensor:
+    def _latents_autograd(self, data: dict[str, torch.Tensor]) -> tuple[torch.Tensor, int, int]:
+        """aggregate_features + transformer_forward up to (not including) the final ScaleNorm: f32 [B*T, hidden]."""
         from modeling_utils import autograd as ag
 
         cfg = self.config
@@ -220,9 +221,16 @@ class FmriEncoder(nn.Module):
             x = ag.Linear.apply(ao, attn.to_out.weight, None, x, res_a.residual_scale, True)
             xn = ag.ScaleNorm.apply(x, norms_f[0].g, gs, eps)
             x = ag.FeedForward.apply(xn, ff.ff[0][0].weight, ff.ff[0][0].bias, ff.ff[2].weight, ff.ff[2].bias, x, res_f.residual_scale)
-        y = ag.ScaleNorm.apply(x, enc.final_norm.g, gs, eps)
+        return x, B, T
+
+    def _forward_autograd(self, data: dict[str, torch.Tensor], pool_outputs: bool) -> torch.Tensor:
+        from modeling_utils import autograd as ag
+
+        x, B, T = self._latents_autograd(data)
+        enc = self.encoder
+        y = ag.ScaleNorm.apply(x, enc.final_norm.g, enc.final_norm.gain_scale, enc.final_norm.eps)
         out = ag.VoxelHead.apply(y.view(B, T, -1), self.predictor.weights, self.predictor.bias,
-                                 self.predictor.check_subjects(subject_id))
+                                 self.predictor.check_subjects(data["subject_id"]))
         if pool_outputs and T != self.n_output_timesteps:
             out = ag.AdaptivePool.apply(out, self.n_output_timesteps)
         return out
@@ -263,20 +271,41 @@ class FmriEncoder(nn.Module):
 
     @staticmethod
     def _info_nce(q: torch.Tensor, k: torch.Tensor, tau: float = 0.07) -> torch.Tensor:
-        """model.py:208-221.  Training-only diagnostic; stock torch ops (outside the HIP inference path)."""
-        import torch.nn.functional as F
+        """model.py:208-221: symmetric InfoNCE over flattened [B, T, H] sequences (HIP: row normalisation, logits MFMA
+        GEMM, log-sum-exp kernels; differentiable through modeling_utils.autograd.InfoNCE)."""
+        from modeling_utils import autograd as ag
 
         bt, h = q.shape[0] * q.shape[1], q.shape[2]
-        q = F.normalize(q.reshape(bt, h), dim=-1)
-        k = F.normalize(k.reshape(bt, h), dim=-1)
-        logits = (q @ k.t()) / tau
-        labels = torch.arange(logits.size(0), device=logits.device)
-        return 0.5 * (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels))
+        return ag.InfoNCE.apply(q.reshape(bt, h).float().contiguous(), k.reshape(bt, h).float().contiguous(), tau)
+
+    def _contrastive_autograd(self, data: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+        """model.py:223-241 on the training path: a SECOND pass through aggregate_features + encoder (fresh
+        modality-dropout draws, as the reference's get_brain_latents does, model.py:177-182,228), the contrastive heads
+        and the symmetric InfoNCE -- all differentiable HIP functions."""
+        from modeling_utils import autograd as ag
+
+        x, B, T = self._latents_autograd(data)
+        enc = self.encoder
+        brain = ag.ScaleNorm.apply(x, enc.final_norm.g, enc.final_norm.gain_scale, enc.final_norm.eps, True)  # f32 [B*T, H]
+        losses: dict[str, torch.Tensor] = {}
+        for modality in self.config.contrastive_modalities:
+            if modality not in self.contrastive_heads or modality not in data:
+                continue
+            feat = data[modality]
+            if feat.shape[-1] != T:
+                raise NotImplementedError("contrastive training with a modality at a different time resolution")
+            packed = ops.pack_features(feat.contiguous(), layer_mean=self.config.layer_aggregation == "mean")
+            head = self.contrastive_heads[modality]
+            lat = ag.ProjectorFuse.apply(packed, head.weight, head.bias)
+            losses[modality] = ag.InfoNCE.apply(brain, lat, self.config.contrastive_temperature)
+        return losses
 
     def compute_contrastive_loss(self, batch: SegmentData | dict) -> dict[str, torch.Tensor]:
         if not self.config.contrastive_enabled:
             return {}
         data = self._batch_dict(batch)
+        if self._wants_grad():
+            return self._contrastive_autograd(data)
         brain = self.get_brain_latents(batch)
         losses: dict[str, torch.Tensor] = {}
         for modality in self.config.contrastive_modalities:

@@ -94,9 +94,7 @@ class BrainModule(nn.Module):
 
     def training_step(self, batch: SegmentData, batch_idx: int):
         """pl_module.py:126-128: returns the loss tensor; `loss.backward()` then runs the HIP backward kernels through
-        the autograd functions of modeling_utils/autograd.py (MSE loss, contrastive branch disabled)."""
-        if getattr(getattr(self.model, "config", None), "contrastive_enabled", False):
-            raise NotImplementedError("training with the contrastive branch is not built yet (SURVEY.md section 8(f))")
+        the autograd functions of modeling_utils/autograd.py (MSE / Pearson loss + optional InfoNCE alignment)."""
         loss, _, _ = self._run_step(batch, batch_idx, step_name="train")
         return loss
 

@@ -149,6 +149,61 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, int64_t n4, unsign
   }
 }
 
+// one workgroup per voxel: d(1 - r)/dx_i = -( yc_i / den - cov * sy * xc_i / (sx * den^2) ),  den = sx * sy + 1e-8
+__global__ __launch_bounds__(256) void pearson_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                               int64_t B, int64_t V, int64_t T, int64_t sb, int64_t sv, int64_t st,
+                                                               const double* __restrict__ stats, float w, const float* __restrict__ gs,
+                                                               float* __restrict__ dpred) {
+  const int64_t v = blockIdx.x;
+  const double* s = stats + v * 6;
+  const double n = s[5];
+  const double mx = s[0] / n, my = s[1] / n;
+  const double cov = s[4] - s[0] * s[1] / n;
+  double vx = s[2] - s[0] * s[0] / n, vy = s[3] - s[1] * s[1] / n;
+  vx = vx > 0.0 ? vx : 0.0;
+  vy = vy > 0.0 ? vy : 0.0;
+  const float sx = sqrtf((float)vx), sy = sqrtf((float)vy);
+  const float den = sx * sy + 1e-8f;
+  const float k = gs[0] * w;
+  const float a = -k / den;                                               // * yc_i
+  const float c = (sx > 0.f) ? k * (float)cov * sy / (sx * den * den) : 0.f;  // * xc_i
+  for (int64_t b = 0; b < B; ++b)
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+      const float xc = pred[b * sb + v * sv + t * st] - (float)mx, yc = truth[b * sb + v * sv + t * st] - (float)my;
+      dpred[(b * V + v) * T + t] = a * yc + c * xc;
+    }
+}
+
+__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ S, int64_t N, int64_t ld, float* __restrict__ lse,
+                                                       float* __restrict__ diag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* s = S + row * ld;
+  float m = -INFINITY;
+  for (int64_t i = lane; i < N; i += 64) m = fmaxf(m, s[i]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int64_t i = lane; i < N; i += 64) sum += __expf(s[i] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) { lse[row] = m + logf(sum); if (diag) diag[row] = s[row]; }
+}
+
+__global__ __launch_bounds__(256) void infonce_dlogits_kernel(const float* __restrict__ S, int64_t N, int64_t ld,
+                                                              const float* __restrict__ lse_r, const float* __restrict__ lse_c,
+                                                              const float* __restrict__ gs, unsigned short* __restrict__ dL, int64_t N_pad) {
+  const int64_t i = blockIdx.x;
+  const float k = gs[0] * 0.5f / (float)N, lr = lse_r[i];
+  for (int64_t j = threadIdx.x; j < N_pad; j += blockDim.x) {
+    float v = 0.f;
+    if (j < N) {
+      const float s = S[i * ld + j];
+      v = k * (__expf(s - lr) + __expf(s - lse_c[j]) - (i == j ? 2.0f : 0.0f));
+    }
+    dL[i * N_pad + j] = f32_to_bf16(v);
+  }
+}
+
 inline unsigned grid_for(int64_t total, int block) {
   int64_t b = (total + block - 1) / block;
   if (b > 256 * 8) b = 256 * 8;
@@ -245,6 +300,31 @@ extern "C" int tribe_adaptive_avg_pool_bwd(const float* dy, int64_t rows, int64_
 extern "C" int tribe_rowsum_scatter(const float* x, int64_t B, int64_t V, int64_t T, const int64_t* idx, float* out, void* stream) {
   TRIBE_REQUIRE(x && idx && out && B > 0 && V > 0 && T > 0 && B < 65536, "tribe_rowsum_scatter: bad argument");
   hipLaunchKernelGGL(rowsum_scatter_kernel, dim3((unsigned)((B * V + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, B, V, T, idx, out);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_pearson_loss_bwd(const float* pred, const float* truth, int64_t B, int64_t V, int64_t T, int64_t sb, int64_t sv,
+                                      int64_t st, const double* stats, int32_t reduction_sum, const float* gscale, float* dpred,
+                                      void* stream) {
+  TRIBE_REQUIRE(pred && truth && stats && gscale && dpred && B > 0 && V > 0 && T > 0, "tribe_pearson_loss_bwd: bad argument");
+  hipLaunchKernelGGL(pearson_loss_bwd_kernel, dim3((unsigned)V), dim3(256), 0, (hipStream_t)stream, pred, truth, B, V, T, sb, sv, st, stats,
+                     reduction_sum ? 1.0f : 1.0f / (float)V, gscale, dpred);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_lse_rows_fwd(const float* S, int64_t N, int64_t ld, float* lse, float* diag, void* stream) {
+  TRIBE_REQUIRE(S && lse && N > 0 && ld >= N, "tribe_lse_rows_fwd: bad argument");
+  hipLaunchKernelGGL(lse_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, N, ld, lse, diag);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_infonce_dlogits(const float* S, int64_t N, int64_t ld, const float* lse_r, const float* lse_c, const float* gscale,
+                                     uint16_t* dL, int64_t N_pad, void* stream) {
+  TRIBE_REQUIRE(S && lse_r && lse_c && gscale && dL && N > 0 && ld >= N && N_pad >= N && N < (1ll << 31), "tribe_infonce_dlogits: bad argument");
+  hipLaunchKernelGGL(infonce_dlogits_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, S, N, ld, lse_r, lse_c, gscale, dL, N_pad);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

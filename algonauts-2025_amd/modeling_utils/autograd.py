@@ -384,6 +384,83 @@ class MSE(torch.autograd.Function):
         return dp, None
 
 
+class PearsonLossFn(torch.autograd.Function):
+    """PearsonLoss over the '(b t) d' view of strided [B, V, T] tensors (losses.py:17-42)."""
+
+    @staticmethod
+    def forward(ctx, pred, true, reduction: str):
+        out = ops.pearson_loss(pred, true, reduction)
+        ctx.save_for_backward(pred, true)
+        ctx.reduction = reduction
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, true = ctx.saved_tensors
+        B, V, T = pred.shape
+        sb, sv, st = pred.stride()
+        stats = torch.zeros(1, V, 6, dtype=torch.float64, device=pred.device)
+        ops.pearson_stats_update(stats, pred, true)
+        dp = torch.empty(B, V, T, dtype=torch.float32, device=pred.device)
+        g = g.reshape(1).to(torch.float32).contiguous()
+        check(lib().tribe_pearson_loss_bwd(pred.data_ptr(), true.data_ptr(), B, V, T, sb, sv, st, stats.data_ptr(), int(ctx.reduction == "sum"),
+                                           g.data_ptr(), dp.data_ptr(), _s()), "tribe_pearson_loss_bwd")
+        if (sb, sv, st) != (V * T, T, 1):  # gradient in the layout of the (strided) input view
+            dp = dp.as_strided((B, V, T), (V * T, T, 1))
+            out = torch.empty_strided((B, V, T), (sb, sv, st), dtype=torch.float32, device=pred.device)
+            out.copy_(dp)
+            dp = out
+        return dp, None, None
+
+
+class InfoNCE(torch.autograd.Function):
+    """Symmetric InfoNCE of model.py:208-221 on two [N, H] f32 latent matrices (rows are L2-normalised here)."""
+
+    @staticmethod
+    def forward(ctx, q, k, tau: float):
+        N, H = q.shape
+        dev = q.device
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        qn = ops.scalenorm(q.contiguous(), one, 1.0, 1e-12, torch.bfloat16)   # F.normalize(dim=-1)
+        kn = ops.scalenorm(k.contiguous(), one, 1.0, 1e-12, torch.bfloat16)
+        S = torch.empty(N, N, dtype=torch.float32, device=dev)
+        St = torch.empty(N, N, dtype=torch.float32, device=dev)
+        _gemm(qn, kn, S, lda=H, ldb=H, ldc=N, M=N, N=N, K=H, alpha=1.0 / tau)
+        _gemm(kn, qn, St, lda=H, ldb=H, ldc=N, M=N, N=N, K=H, alpha=1.0 / tau)   # logits^T: its row LSE = column LSE of logits
+        lse_r, lse_c, diag = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+        check(lib().tribe_lse_rows_fwd(S.data_ptr(), N, N, lse_r.data_ptr(), diag.data_ptr(), _s()), "tribe_lse_rows_fwd")
+        check(lib().tribe_lse_rows_fwd(St.data_ptr(), N, N, lse_c.data_ptr(), None, _s()), "tribe_lse_rows_fwd")
+        del St
+        loss = 0.5 * ((lse_r - diag).mean() + (lse_c - diag).mean())  # two length-N vector reductions (host glue)
+        ctx.save_for_backward(q, k, qn, kn, S, lse_r, lse_c)
+        ctx.tau = tau
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, qn, kn, S, lse_r, lse_c = ctx.saved_tensors
+        N, H = q.shape
+        dev = q.device
+        Np = ops.round_up(N, 64)
+        gs = (g.reshape(1).to(torch.float32) / ctx.tau).contiguous()   # d logits / d (q.k) = 1 / tau
+        dL = torch.empty(N, Np, dtype=torch.bfloat16, device=dev)
+        check(lib().tribe_infonce_dlogits(S.data_ptr(), N, N, lse_r.data_ptr(), lse_c.data_ptr(), gs.data_ptr(), dL.data_ptr(), Np, _s()),
+              "tribe_infonce_dlogits")
+        knT = transpose_bf16(kn, 1, N, H, 0, H)[0]   # [H, Np]
+        qnT = transpose_bf16(qn, 1, N, H, 0, H)[0]
+        dLT = transpose_bf16(dL, 1, N, N, 0, Np)[0]  # [N, Np]
+        dqn = torch.empty(N, H, dtype=torch.float32, device=dev)
+        dkn = torch.empty(N, H, dtype=torch.float32, device=dev)
+        _gemm(dL, knT, dqn, lda=Np, ldb=Np, ldc=H, M=N, N=H, K=Np)    # dq^ = dL k^
+        _gemm(dLT, qnT, dkn, lda=Np, ldb=Np, ldc=H, M=N, N=H, K=Np)   # dk^ = dL^T q^
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        for x, dy, dx in ((q, dqn, dq), (k, dkn, dk)):
+            check(lib().tribe_scalenorm_bwd(x.data_ptr(), dy.data_ptr(), F32, one.data_ptr(), 1.0, 1e-12, N, H, None, None, dx.data_ptr(), None,
+                                            _s()), "tribe_scalenorm_bwd")
+        return dq, dk, None
+
+
 class ProjectorFuse(torch.autograd.Function):
     """One modality's projector writing its column slice of the fused stream (+ positional / subject embeddings are
     added by EmbedAdd).  feat bf16 [M, Kp]; W f32 [N, K]; out slice f32 [M, N] (a fresh tensor; concat is done by cat)."""

@@ -7,7 +7,7 @@ counterpart of `torch.nn.MSELoss()` selected by defaults.py:125.
 Both accept what the reference passes -- two [N, V] matrices, columns = voxels -- and, as the
 fast path used by BrainModule, the un-flattened [B, V, T'] pair via `forward_bvt` (the '(b t) d'
 flatten of pl_module.py:54-55 is a pure re-indexing of the same sums and is never materialised).
-`MSELoss` is differentiable (HIP backward kernel); `PearsonLoss` is forward only so far.
+Both are differentiable (HIP backward kernels, modeling_utils/autograd.py).
 """
 
 from __future__ import annotations
@@ -36,6 +36,10 @@ class PearsonLoss(nn.Module):
     def forward_bvt(self, pred: torch.Tensor, true: torch.Tensor) -> torch.Tensor:
         if self.reduction not in ("mean", "sum"):
             raise ValueError(f"Invalid reduction: {self.reduction}")
+        if torch.is_grad_enabled() and pred.requires_grad:
+            from ..autograd import PearsonLossFn
+
+            return PearsonLossFn.apply(pred.float(), true.float(), self.reduction)
         return ops.pearson_loss(pred.float(), true.float(), self.reduction)
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

@@ -177,6 +177,9 @@ SIGNATURES = {
     "tribe_adaptive_avg_pool_bwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
     "tribe_rowsum_scatter": (C.c_int, [vp, i64, i64, i64, vp, vp, vp]),
     "tribe_scale_cols_fwd": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "tribe_pearson_loss_bwd": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, vp, i32, vp, vp, vp]),
+    "tribe_lse_rows_fwd": (C.c_int, [vp, i64, i64, vp, vp, vp]),
+    "tribe_infonce_dlogits": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp]),
     "tribe_cast_bf16_fwd": (C.c_int, [vp, i64, vp, vp]),
     "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
     "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),

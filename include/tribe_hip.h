@@ -378,6 +378,16 @@ int tribe_adaptive_avg_pool_bwd(const float* dy, int64_t rows, int64_t T_in, int
 int tribe_rowsum_scatter(const float* x, int64_t B, int64_t V, int64_t T, const int64_t* idx, float* out, void* stream);
 /* y = x * rs (columns), f32 [M, N]; rs NULL = copy */
 int tribe_scale_cols_fwd(const float* x, const float* rs, int64_t M, int64_t N, float* y, void* stream);
+/* PearsonLoss backward (losses.py:17-42) on [B, V, T] views (element strides sb, sv, st shared by pred / true / dpred
+ * which is contiguous [B, V, T]): stats f64 [V, 6] as produced by tribe_pearson_stats_update (one group);
+ * dpred = gscale[0] * w * d(1 - r_v)/d pred,  w = 1/V (mean) or 1 (sum). */
+int tribe_pearson_loss_bwd(const float* pred, const float* truth, int64_t B, int64_t V, int64_t T, int64_t sb, int64_t sv,
+                           int64_t st, const double* stats, int32_t reduction_sum, const float* gscale, float* dpred, void* stream);
+/* InfoNCE pieces (model.py:208-221): lse[r] = log sum_j exp(S[r, j]) and diag[r] = S[r, r] of a square f32 matrix;
+ * dL[i, j] = gscale[0] * 0.5 / N * (exp(S[i,j] - lse_r[i]) + exp(S[i,j] - lse_c[j]) - 2 [i == j])  as bf16 [N, N_pad] */
+int tribe_lse_rows_fwd(const float* S, int64_t N, int64_t ld, float* lse, float* diag, void* stream);
+int tribe_infonce_dlogits(const float* S, int64_t N, int64_t ld, const float* lse_r, const float* lse_c, const float* gscale,
+                          uint16_t* dL, int64_t N_pad, void* stream);
 /* f32 -> bf16 elementwise (gradient casts) */
 int tribe_cast_bf16_fwd(const float* x, int64_t n, uint16_t* y, void* stream);
 

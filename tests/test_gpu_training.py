@@ -116,3 +116,65 @@ def test_training_step_gradients_vs_oracle(cfg_kw):
     bad = {k: v for k, v in worst.items() if v > 6e-2}
     assert not bad, f"gradient mismatch: {bad}"
     print("max grad rel err", max(worst.values()), "over", len(worst), "tensors")
+
+
+def test_pearson_loss_and_infonce_gradients():
+    from modeling_utils import autograd as ag
+    from modeling_utils.losses import PearsonLoss
+
+    g = torch.Generator().manual_seed(3)
+    B, V, T = 3, 17, 40
+    pred = torch.randn(B, V, T, generator=g); true = 0.4 * pred + torch.randn(B, V, T, generator=g)
+    for reduction in ("mean", "sum"):
+        pt = pred.clone().requires_grad_()
+        tribe_ref.pearson_loss(tribe_ref.flatten_bt(pt), tribe_ref.flatten_bt(true), reduction).backward()
+        pg = pred.cuda().requires_grad_()
+        loss = PearsonLoss(reduction).forward_bvt(pg, true.cuda())
+        loss.backward()
+        torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=2e-4, atol=1e-6)
+    # InfoNCE (model.py:208-221) incl. the row normalisation
+    N, H = 150, 128
+    q = torch.randn(N, H, generator=g); k = 0.7 * q + torch.randn(N, H, generator=g)
+    qt, kt = q.clone().requires_grad_(), k.clone().requires_grad_()
+    want = tribe_ref.info_nce(qt[None], kt[None], 0.07)
+    want.backward()
+    qg, kg = q.cuda().requires_grad_(), k.cuda().requires_grad_()
+    got = ag.InfoNCE.apply(qg, kg, 0.07)
+    got.backward()
+    assert abs(float(got.detach()) - float(want.detach())) < 2e-2 * abs(float(want.detach()))  # bf16-rounded unit vectors, logits / 0.07
+    assert _rel(qg.grad.cpu(), qt.grad) < 5e-2 and _rel(kg.grad.cpu(), kt.grad) < 5e-2
+
+
+def test_training_step_with_contrastive_branch():
+    """defaults.py:101-105 enables the InfoNCE alignment with the video modality: loss = mse + 0.1 * info_nce."""
+    from algonauts2025.model import FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from data_utils.dataloader import SegmentData
+    from modeling_utils.losses import TorchLossConfig
+
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    V, Tout, S, B, T = 50, 10, 3, 4, 31
+    dims = tribe_ref.EncoderDims(hidden=768, depth=2, heads=4)
+    ref = tribe_ref.FmriEncoderRef(fdims, V, Tout, S, contrastive_modalities=["video"], dims=dims).train()
+    with torch.no_grad():
+        tribe_ref.fill_params_(ref, seed=2)
+    model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=2, heads=4, contrastive_enabled=True).build(fdims, V, Tout)
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda().train()
+    data = tribe_ref.synthetic_batch(B, T, fdims, S, seed=4)
+    fmri = torch.randn(B, V, Tout, generator=torch.Generator().manual_seed(9))
+    mse, *_ = tribe_ref.run_step(ref(data), fmri, data["subject_id"])
+    nce = ref.compute_contrastive_loss(data)["video"]
+    loss_ref = mse + 0.1 * nce  # pl_module.py:58-77
+    loss_ref.backward()
+    bm = BrainModule(model, TorchLossConfig(name="MSELoss").build(), None, {})
+    batch = SegmentData(data={**{k: v.cuda() for k, v in data.items()}, "fmri": fmri.cuda()}, segments=[None] * B)
+    loss = bm.training_step(batch, 0)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-2 * float(loss_ref.detach())
+    loss.backward()
+    ref_grads = dict(ref.named_parameters())
+    worst = {n: _rel(p.grad.cpu(), ref_grads[n].grad) for n, p in model.named_parameters() if ref_grads[n].grad is not None}
+    assert "contrastive_heads.video.weight" in worst
+    bad = {k: v for k, v in worst.items() if v > 8e-2}
+    assert not bad, f"gradient mismatch: {bad}"
+    print("contrastive: max grad rel err", max(worst.values()))
