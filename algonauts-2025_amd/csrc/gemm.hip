@@ -23,6 +23,7 @@
 namespace {
 
 constexpr int BK = 64;
+constexpr int TRIBE_ROLE_EXT = 100;  // kernel instantiation carrying the extended epilogue (see gemm_common.h)
 
 // =============================================================================================
 // 256 x 256 x 64, counted-vmcnt pipeline
@@ -231,11 +232,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   // through LDS to get whole-row 256-byte stores was measured 2x SLOWER (K = 64 probe: 158 vs 75 us f32, 138 vs 43 us
   // bf16 per 16384 x 3072 output): the extra LDS round trip costs more than the wider store segments save.
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue_tile16<OUT_BF16>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * 64 + j * 16, lane);
+  static_for<32>([&](auto t) {
+    constexpr int i = decltype(t)::value / 4, j = decltype(t)::value % 4;
+    epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * 64 + j * 16, lane);
+  });
 }
 
 // =============================================================================================
@@ -332,11 +332,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
   }
 
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue_tile16<OUT_BF16>(g, ctx, acc[i][j], m0 + wr * 64 + i * 16, n0 + wc * 64 + j * 16, lane);
+  static_for<16>([&](auto t) {
+    constexpr int i = decltype(t)::value / 4, j = decltype(t)::value % 4;
+    epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc[i][j], m0 + wr * 64 + i * 16, n0 + wc * 64 + j * 16, lane);
+  });
 }
 
 }  // namespace
@@ -457,6 +456,11 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
     else TRIBE_GEMM_LAUNCH_K(gemm_nt_128x128x64, 256, small::SMEM_BYTES, BF, ROLE);                          \
   } while (0)
   const bool bf = d->c_dtype == TRIBE_BF16;
+  const bool ext = d->aux != nullptr || d->act == TRIBE_ACT_SWIGLU || d->act == TRIBE_ACT_GLU || d->act == TRIBE_ACT_SILU ||
+                   d->act == TRIBE_ACT_GELU_BWD;
+  if (ext) {
+    if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_EXT); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_EXT);
+  } else
   switch (role) {
     case TRIBE_ROLE_PROJECTOR: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_PROJECTOR); break;
     case TRIBE_ROLE_QKV: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_QKV); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;

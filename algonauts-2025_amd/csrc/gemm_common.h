@@ -2,6 +2,7 @@
 // XCD-aware tile remap.
 #pragma once
 #include "common.h"
+#include <utility>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -115,7 +116,10 @@ __device__ __forceinline__ void quad_transpose(f32x4_t acc, float alpha, int lan
 
 // epilogue of 4 consecutive columns n..n+3 of row m (values already scaled by alpha): bias, activation, residual,
 // row / gathered adds, store.
-template <int OUT_BF16>
+// EXT = 0 compiles only the operators of the encode hot path (bias, GELU, scaled residual, row / gathered adds);
+// EXT = 1 adds the rarely used ones (SwiGLU / GLU / SiLU, GELU' with the saved pre-activation, pre-activation store).
+// Keeping them out of the hot kernels keeps their code (and SGPR pressure) small.
+template <int OUT_BF16, int EXT>
 __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const EpiCtx& c, float (&v)[4], int64_t m, int64_t n) {
   if (m >= g.M || n >= g.N) return;
   if (g.bias_mode == TRIBE_BIAS_ROW) {
@@ -131,7 +135,7 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
       const float4 b = *(const float4*)(c.bias + n);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU) {
+    if (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU)) {
       // column pairs -> two outputs at columns n/2, n/2 + 1 of a C that is N/2 wide:
       // SwiGLU silu(gate) * up (LlamaMLP, modeling_llama.py:177); GLU a * sigmoid(b) (nn.GLU in the conformer conv module)
       const bool glu = g.act == TRIBE_ACT_GLU;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
       return;
     }
     if (g.act == TRIBE_ACT_GELU) {
-      if (g.aux) {  // training forward: keep the pre-activation for the backward pass
+      if (EXT && g.aux) {  // training forward: keep the pre-activation for the backward pass
         u16x4_t pre;
 #pragma unroll
         for (int k = 0; k < 4; ++k) pre[k] = f32_to_bf16(v[k]);
@@ -155,11 +159,11 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = OUT_BF16 ? gelu_fast(v[k]) : gelu_erf(v[k]);
-    } else if (g.act == TRIBE_ACT_GELU_BWD) {
+    } else if (EXT && g.act == TRIBE_ACT_GELU_BWD) {
       const u16x4_t pre = *(const u16x4_t*)((const unsigned short*)g.aux + c.c_off + m * g.ld_aux + n);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] *= gelu_grad(bf16_to_f32(pre[k]));
-    } else if (g.act == TRIBE_ACT_SILU) {
+    } else if (EXT && g.act == TRIBE_ACT_SILU) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
     }
@@ -190,7 +194,7 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
     }
     return;
   }
-  if (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU) {
+  if (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU)) {
 #pragma unroll
     for (int k = 0; k < 4; k += 2) {
       if (n + k + 1 >= g.N) break;
@@ -209,11 +213,11 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
     float x = v[k];
     if (g.bias_mode == TRIBE_BIAS_COL) x += c.bias[n + k];
     if (g.act == TRIBE_ACT_GELU) {
-      if (g.aux) ((unsigned short*)g.aux)[c.c_off + m * g.ld_aux + n + k] = f32_to_bf16(x);
+      if (EXT && g.aux) ((unsigned short*)g.aux)[c.c_off + m * g.ld_aux + n + k] = f32_to_bf16(x);
       x = OUT_BF16 ? gelu_fast(x) : gelu_erf(x);
-    } else if (g.act == TRIBE_ACT_GELU_BWD) {
+    } else if (EXT && g.act == TRIBE_ACT_GELU_BWD) {
       x *= gelu_grad(bf16_to_f32(((const unsigned short*)g.aux)[c.c_off + m * g.ld_aux + n + k]));
-    } else if (g.act == TRIBE_ACT_SILU) x = silu_f(x);
+    } else if (EXT && g.act == TRIBE_ACT_SILU) x = silu_f(x);
     if (c.res) {
       const float r = c.res[m * g.ldres + n + k];
       x += g.res_scale ? r * g.res_scale[n + k] : r;
@@ -225,11 +229,24 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
   }
 }
 
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The epilogues index the
+// accumulator array with these constants, so the accumulators stay in registers whatever the unroller decides
+// ("#pragma unroll" gives up above its size threshold; the accumulators then move to scratch and the epilogue
+// becomes a loop over scratch loads -- that cost 528 B/lane of scratch and 20 % of the 256 x 256 kernel once).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).
-template <int OUT_BF16>
+template <int OUT_BF16, int EXT>
 __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t acc, int64_t mt0,
                                                 int64_t nt0, int lane) {
   float v[4];
   quad_transpose(acc, g.alpha, lane, v);
-  epilogue_row4<OUT_BF16>(g, c, v, mt0 + ((lane >> 4) << 2) + (lane & 3), nt0 + (((lane & 15) >> 2) << 2));
+  epilogue_row4<OUT_BF16, EXT>(g, c, v, mt0 + ((lane >> 4) << 2) + (lane & 3), nt0 + (((lane & 15) >> 2) << 2));
 }
