@@ -97,6 +97,18 @@ class FmriEncoder(nn.Module):
     def _batch_dict(self, batch: SegmentData | dict) -> dict[str, torch.Tensor]:
         return batch.data if hasattr(batch, "data") else batch
 
+    def _pack(self, feat: tp.Any) -> torch.Tensor:
+        """features -> bf16 [B*T, K_pad] projector operand (model.py:146-155).  Batches from the GPU segment loader
+        (data_utils/gpu_loader.py: `PackedFeature`) already are in that layout and skip the pass."""
+        mean = self.config.layer_aggregation == "mean"
+        if hasattr(feat, "packed"):
+            if not mean or feat.L == 1:
+                return feat.packed
+            feat = feat.unpack()
+        if feat.ndim not in (3, 4):
+            raise AssertionError(f"expected [B, L, D, T] or [B, D, T] features, got {tuple(feat.shape)}")
+        return ops.pack_features(feat.contiguous(), layer_mean=mean)
+
     def _packed_linear(self, key: str, lin: nn.Linear) -> tuple[torch.Tensor, torch.Tensor]:
         return self._packs.get(key, [lin.weight, lin.bias], lambda: (ops.pack_weight(f32c(lin.weight)), f32c(lin.bias)))
 
@@ -148,7 +160,7 @@ class FmriEncoder(nn.Module):
                 feat = data[modality]
                 if feat.ndim not in (3, 4):
                     raise AssertionError(f"expected [B, L, D, T] or [B, D, T] features, got {tuple(feat.shape)}")
-                packed = ops.pack_features(feat.contiguous(), layer_mean=self.config.layer_aggregation == "mean")
+                packed = self._pack(feat)
                 w, b = self._packed_linear(f"proj.{modality}", self.projectors[modality])
                 ops.projector_fwd(packed, T, w, b, n_out, x, col0, accumulate=(not cat and not first), pos_embed=emb[0],
                                   subj_embed=emb[1], subject_id=emb[2])
@@ -196,7 +208,7 @@ class FmriEncoder(nn.Module):
             if m not in self.projectors or m in dropped:  # model.py:143-144,158-159: zero block, no gradient
                 slices.append(torch.zeros(B * T, slot, dtype=torch.float32, device=ref.device))
                 continue
-            packed = ops.pack_features(data[m].contiguous(), layer_mean=cfg.layer_aggregation == "mean")
+            packed = self._pack(data[m])
             lin = self.projectors[m]
             slices.append(ag.ProjectorFuse.apply(packed, lin.weight, lin.bias))
         x = torch.cat(slices, dim=1).view(B, T, n_mod * slot)
@@ -263,7 +275,7 @@ class FmriEncoder(nn.Module):
         if feat is None:
             raise KeyError(f"Modality '{modality}' not found in batch.data")
         B, T = feat.shape[0], feat.shape[-1]
-        packed = ops.pack_features(feat.contiguous(), layer_mean=self.config.layer_aggregation == "mean")
+        packed = self._pack(feat)
         w, b = self._packed_linear(f"chead.{modality}", self.contrastive_heads[modality])
         out = torch.empty(B * T, self.hidden, dtype=torch.float32, device=feat.device)
         ops.projector_fwd(packed, T, w, b, self.hidden, out, 0, False, None, None, None)
@@ -294,7 +306,7 @@ class FmriEncoder(nn.Module):
             feat = data[modality]
             if feat.shape[-1] != T:
                 raise NotImplementedError("contrastive training with a modality at a different time resolution")
-            packed = ops.pack_features(feat.contiguous(), layer_mean=self.config.layer_aggregation == "mean")
+            packed = self._pack(feat)
             head = self.contrastive_heads[modality]
             lat = ag.ProjectorFuse.apply(packed, head.weight, head.bias)
             losses[modality] = ag.InfoNCE.apply(brain, lat, self.config.contrastive_temperature)

@@ -11,6 +11,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
+import numpy as _np
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libtribe_hip.so"
 
@@ -20,6 +22,11 @@ BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head"]
 
 i64, i32, f32, vp, sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
+
+
+# tribe_feature_piece as a numpy record (tables of pieces are built vectorised on the host and uploaded as bytes)
+FEATURE_PIECE_DTYPE = _np.dtype([("src", "<u8"), ("ld", "<i8"), ("src_first", "<i4"), ("src_count", "<i4"), ("dst_first", "<i4"),
+                                 ("dst_count", "<i4")], align=True)
 
 
 class GemmDesc(C.Structure):
@@ -181,6 +188,9 @@ SIGNATURES = {
     "tribe_lse_rows_fwd": (C.c_int, [vp, i64, i64, vp, vp, vp]),
     "tribe_infonce_dlogits": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp]),
     "tribe_cast_bf16_fwd": (C.c_int, [vp, i64, vp, vp]),
+    "tribe_group_mean_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, vp, vp]),
+    "tribe_segment_gather_fwd": (C.c_int, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),
+    "tribe_word_bag_fwd": (C.c_int, [vp, i64, i64, vp, vp, i64, vp, i64, vp]),
     "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
     "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),

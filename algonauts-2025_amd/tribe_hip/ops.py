@@ -430,3 +430,57 @@ def prof_end() -> dict[str, dict[str, float]]:
 
 __all__ = [n for n in dir() if not n.startswith("_")]
 _ = tp
+
+
+# --------------------------------------------------------------------------------------
+# segment assembly from HBM-resident extractor outputs (csrc/features.hip)
+# --------------------------------------------------------------------------------------
+def group_mean(states: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
+    """states f32 [batch, n_states, plane...] -> f32 [batch, n_groups, plane...]: mean over layers lo[g]..hi[g]-1
+    (`_aggregate_layers`, text.py:129-149).  lo / hi int32 device tensors."""
+    _cuda(states, torch.float32, "states")
+    _cuda(lo, torch.int32, "lo")
+    _cuda(hi, torch.int32, "hi")
+    if states.ndim < 3 or lo.shape != hi.shape or lo.ndim != 1:
+        raise ValueError(f"group_mean: states {tuple(states.shape)} / bounds {tuple(lo.shape)}, {tuple(hi.shape)}")
+    batch, n_states = states.shape[:2]
+    plane = states[0, 0].numel()
+    out = torch.empty((batch, lo.numel()) + tuple(states.shape[2:]), dtype=torch.float32, device=states.device)
+    check(lib().tribe_group_mean_fwd(states.data_ptr(), batch, n_states, plane, lo.data_ptr(), hi.data_ptr(), lo.numel(), out.data_ptr(),
+                                     _stream()), "tribe_group_mean_fwd")
+    return out
+
+
+def segment_gather(pieces: torch.Tensor, seg_ptr: torch.Tensor, B: int, C: int, T: int, packed: bool, C_pad: int | None = None) -> torch.Tensor:
+    """Sum time slices of cached arrays into segment outputs.  pieces: uint8 device tensor holding `tribe_feature_piece`
+    records, seg_ptr int32 [B + 1].  packed -> bf16 [B*T, C_pad]; else f32 [B, C, T]."""
+    _cuda(pieces, torch.uint8, "pieces")
+    _cuda(seg_ptr, torch.int32, "seg_ptr")
+    if seg_ptr.numel() != B + 1 or pieces.numel() % _lib.FEATURE_PIECE_DTYPE.itemsize:
+        raise ValueError("segment_gather: seg_ptr must hold B + 1 offsets and pieces whole records")
+    if packed:
+        C_pad = round_up(C, 64) if C_pad is None else C_pad
+        out = torch.empty(B * T, C_pad, dtype=torch.bfloat16, device=pieces.device)
+    else:
+        C_pad = C
+        out = torch.empty(B, C, T, dtype=torch.float32, device=pieces.device)
+    check(lib().tribe_segment_gather_fwd(pieces.data_ptr(), seg_ptr.data_ptr(), B, C, T, out.data_ptr(), BF16 if packed else F32, C_pad,
+                                         _stream()), "tribe_segment_gather_fwd")
+    return out
+
+
+def word_bag(table: torch.Tensor, row_ptr: torch.Tensor, word_idx: torch.Tensor, rows: int, C_pad: int | None = None) -> torch.Tensor:
+    """table f32 [n_words, C]; CSR (row_ptr int32 [rows + 1], word_idx int32) -> bf16 [rows, C_pad] row sums."""
+    _cuda(table, torch.float32, "table")
+    _cuda(row_ptr, torch.int32, "row_ptr")
+    _cuda(word_idx, torch.int32, "word_idx")
+    if table.ndim != 2 or row_ptr.numel() != rows + 1:
+        raise ValueError(f"word_bag: table {tuple(table.shape)}, row_ptr {tuple(row_ptr.shape)} for {rows} rows")
+    n_words, C = table.shape
+    C_pad = round_up(C, 64) if C_pad is None else C_pad
+    out = torch.empty(rows, C_pad, dtype=torch.bfloat16, device=table.device)
+    if word_idx.numel() == 0:   # no word overlaps any row: the output is all zeros (and the kernel would get a null list)
+        return out.zero_()
+    check(lib().tribe_word_bag_fwd(table.data_ptr(), n_words, C, row_ptr.data_ptr(), word_idx.data_ptr(), rows, out.data_ptr(), C_pad,
+                                   _stream()), "tribe_word_bag_fwd")
+    return out

@@ -391,6 +391,42 @@ int tribe_infonce_dlogits(const float* S, int64_t N, int64_t ld, const float* ls
 /* f32 -> bf16 elementwise (gradient casts) */
 int tribe_cast_bf16_fwd(const float* x, int64_t n, uint16_t* y, void* stream);
 
+/* ---- segment assembly from HBM-resident extractor outputs --------------------------------
+ * Replaces the host-side numpy assembly of a segment's feature tensor: `_aggregate_layers`
+ * (data_utils/features/text.py:129-149, audio.py:174-194, video.py:147-167), `TimedArray.overlap` / `__iadd__`
+ * (data_utils/base.py:130-211) driven by the feature `__call__`s (text.py:85-124, audio.py:78-120, neuro.py:60-106),
+ * plus the fp32 H2D copy and the "b (l d) t -> b t (l d)" transpose of model.py:146-155.  The index decisions
+ * (rounding, clamping) stay on the host (data_utils/base.py of this build); these kernels move the bytes. */
+
+/* one time slice of a cached, layer-aggregated array that lands in a segment's output (32 bytes, device memory) */
+typedef struct tribe_feature_piece {
+  const float* src;   /* device pointer to an f32 [C, ld] array: channel c starts at src + c * ld              */
+  int64_t ld;         /* samples per channel row                                                               */
+  int32_t src_first;  /* first source sample                                                                   */
+  int32_t src_count;  /* == dst_count, or 1 = that one sample is broadcast over the destination run            */
+  int32_t dst_first;  /* first destination step (0 <= dst_first, dst_first + dst_count <= T)                   */
+  int32_t dst_count;  /* destination run length                                                                */
+} tribe_feature_piece;
+
+/* out[b, g, i] = mean over s in [lo[g], hi[g]) of states[b, s, i]  (f32; sequential adds in layer order, one divide:
+ * bit-identical to numpy's latents[l1:l2].mean(0)); groups of one select single layers (layer_aggregation = None).
+ * states [batch, n_states, plane], out [batch, n_groups, plane]; lo / hi int32 device arrays of n_groups entries. */
+int tribe_group_mean_fwd(const float* states, int64_t batch, int64_t n_states, int64_t plane, const int32_t* lo,
+                         const int32_t* hi, int32_t n_groups, float* out, void* stream);
+/* Sum the pieces of each segment (seg_ptr: int32 [B + 1] CSR offsets into pieces, in the order the reference adds
+ * them) into a zero-initialised output:
+ *   out_dtype = TRIBE_BF16: packed projector operand, bf16 [B * T, C_pad] rows (time-major, channels contiguous,
+ *                           columns >= C zero) -- what tribe_pack_features would have produced from [B, C, T];
+ *   out_dtype = TRIBE_F32 : reference layout f32 [B, C, T] (targets such as the fMRI array; C_pad ignored).
+ * The caller guarantees src_first + src_count <= ld and the dst bounds above (checked on the host by the binding). */
+int tribe_segment_gather_fwd(const tribe_feature_piece* pieces, const int32_t* seg_ptr, int64_t B, int64_t C, int64_t T,
+                             void* out, int32_t out_dtype, int64_t C_pad, void* stream);
+/* Word features (frequency-0 arrays held for a word's duration, text.py:190-202): out[row] = bf16(sum of
+ * table[word_idx[k]] for k in [row_ptr[row], row_ptr[row + 1])), rows = B * T, table f32 [n_words, C],
+ * out bf16 [rows, C_pad]; lists keep the segment's event order, so the f32 sum is the reference's sum. */
+int tribe_word_bag_fwd(const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
+                       int64_t rows, uint16_t* out, int64_t C_pad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,16 +44,17 @@ def test_ctypes_struct_layout_matches_c(tmp_path):
         #include <stddef.h>
         #include "{HEADER}"
         int main(void) {{
-          printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(tribe_gemm_desc), offsetof(tribe_gemm_desc, alpha),
+          printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(tribe_gemm_desc), offsetof(tribe_gemm_desc, alpha),
                  offsetof(tribe_gemm_desc, ld_gadd), sizeof(tribe_encoder_layer), sizeof(tribe_encoder_desc),
-                 offsetof(tribe_encoder_desc, layers_host));
+                 offsetof(tribe_encoder_desc, layers_host), sizeof(tribe_feature_piece), offsetof(tribe_feature_piece, dst_first));
           return 0;
         }}"""))
     exe = tmp_path / "layout"
     subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [ctypes.sizeof(_lib.GemmDesc), _lib.GemmDesc.alpha.offset, _lib.GemmDesc.ld_gadd.offset,
-            ctypes.sizeof(_lib.EncoderLayer), ctypes.sizeof(_lib.EncoderDesc), _lib.EncoderDesc.layers_host.offset]
+            ctypes.sizeof(_lib.EncoderLayer), ctypes.sizeof(_lib.EncoderDesc), _lib.EncoderDesc.layers_host.offset,
+            _lib.FEATURE_PIECE_DTYPE.itemsize, _lib.FEATURE_PIECE_DTYPE.fields["dst_first"][1]]
     assert got == want
 
 
