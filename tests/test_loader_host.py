@@ -125,3 +125,47 @@ def test_layer_groups_and_store_errors():
     pf = PackedFeature(torch.arange(6 * 64, dtype=torch.float32).view(6, 64).bfloat16(), B=2, L=2, D=3, T=3)
     assert pf.shape == (2, 2, 3, 3) and pf.unpack().shape == (2, 2, 3, 3)
     assert float(pf.unpack()[1, 1, 2, 0]) == float(pf.packed[3, 5])                      # [b, l, d, t] <- row b*T + t, column l*D + d
+
+
+def test_cache_file_round_trip_and_foreign_records(tmp_path):
+    import json
+
+    from data_utils.cache_file import iter_cache, load_into_store, write_cache
+
+    rng = np.random.default_rng(3)
+    items = {"movie0.mkv": rng.standard_normal((5, 6, 17)).astype(np.float32), "movie1.mkv": rng.standard_normal((5, 6, 3)),
+             "w:hello": rng.standard_normal((7, 4)).astype(np.float16)}
+    info = write_cache(tmp_path, items, name="vjepa2")
+    write_cache(tmp_path, {"movie0.mkv": items["movie0.mkv"] + 1}, name="vjepa2")            # re-written item: the later line wins
+    # lines in the shape an exca-style writer is expected to leave: a header line and a record with another key name
+    with open(info, "a") as f:
+        f.write(json.dumps({"cache_type": "MemmapArrayFile"}) + "\n")
+    foreign = tmp_path / "other.data"
+    foreign.write_bytes(b"\0" * 8 + np.arange(6, dtype=np.int32).tobytes())
+    (tmp_path / "other-info.jsonl").write_text(json.dumps({"key": "x", "filename": "other.data", "offset": 8, "shape": [2, 3], "dtype": "int32"}) + "\n")
+    got = dict(iter_cache(tmp_path))
+    assert set(got) == {"movie0.mkv", "movie1.mkv", "w:hello", "x"}
+    assert np.array_equal(got["movie0.mkv"], items["movie0.mkv"] + 1) and got["movie1.mkv"].dtype == np.float64
+    assert np.array_equal(got["w:hello"], items["w:hello"]) and np.array_equal(got["x"], np.arange(6).reshape(2, 3))
+    assert not got["movie1.mkv"].flags.writeable
+    (tmp_path / "bad-info.jsonl").write_text(json.dumps({"#key": "y", "filename": "other.data", "offset": 16, "shape": [9], "dtype": "int32"}) + "\n")
+    with pytest.raises(ValueError):
+        dict(iter_cache(tmp_path))
+    (tmp_path / "bad-info.jsonl").unlink()
+
+    class Store:                                                                             # records what a real HbmFeatureStore would be handed
+        specs = {"video": type("S", (), {"kind": "sampled"})(), "text": type("S", (), {"kind": "words"})()}
+
+        def __init__(self):
+            self.calls = []
+
+        def put(self, name, ev, arr):
+            self.calls.append((name, ev, arr.shape))
+
+        def put_words(self, name, evs, arr):
+            self.calls.append((name, tuple(evs), arr.shape))
+
+    st = Store()
+    assert load_into_store(st, "video", tmp_path, {"movie0.mkv": "E0", "movie1.mkv": "E1"}) == 2
+    assert load_into_store(st, "text", tmp_path, {"w:hello": "W"}) == 1
+    assert st.calls == [("video", "E0", (5, 6, 17)), ("video", "E1", (5, 6, 3)), ("text", ("W",), (1, 7, 4))]
