@@ -1,0 +1,110 @@
+"""The two callbacks either side of the model in the reference's Trainer loop
+(/root/reference/algonauts2025/callbacks.py:16-103), as plain objects with the same hook names and arguments
+(with Lightning installed they can be mixed into `lightning.pytorch.Callback`; nothing here needs it).
+
+* `JitterWindows`: re-cuts the training windows at every epoch start with one random shift of the whole grid.
+* `Benchmark`: collects test predictions per subject and movie chunk and writes the competition's `submission.npy`
+  (+ `.zip`).  Predictions stay on the GPU until a batch is complete: ONE transposing launch
+  (tribe_transpose_f32_fwd, [B, V, T'] -> [B, T', V]) and one device-to-host copy per batch replace the reference's
+  per-segment `.cpu().numpy().T`.
+"""
+
+from __future__ import annotations
+
+import json
+import typing as tp
+import zipfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from data_utils.segments import iter_segments
+from tribe_hip import ops
+
+SUBJECT_MAPPINGS = {0: 1, 1: 2, 2: 3, 3: 5}   # callbacks.py:13
+
+
+class JitterWindows:
+    """callbacks.py:16-44.  `duration_jitter_amount` is drawn (the RNG stream must match) but, as in the reference, unused."""
+
+    def __init__(self, start_jitter_amount: float = 0.0, duration_jitter_amount: float = 0.0) -> None:
+        self.start_jitter_amount = start_jitter_amount
+        self.duration_jitter_amount = duration_jitter_amount
+
+    def on_train_epoch_start(self, trainer: tp.Any, pl_module: tp.Any) -> None:
+        start_jitter = (np.random.rand() * 2 - 1) * self.start_jitter_amount
+        _ = (np.random.rand() * 2 - 1) * self.duration_jitter_amount
+        dataset = trainer.train_dataloader.dataset
+        new_segments = list(iter_segments(dataset.segments, start_jitter=start_jitter))
+        assert len(dataset.segments) == len(new_segments)
+        dataset.segments = new_segments
+
+
+def _first_field(segment: tp.Any, field: str) -> tp.Any:
+    """`segment.events.<field>.unique()[0]` (callbacks.py:61-62): the value carried by the segment's first event."""
+    e = segment.ns_events[0]
+    return getattr(e, field) if hasattr(e, field) else e.extra[field]
+
+
+class Benchmark:
+    """callbacks.py:47-103.  `target_sample_number` (subject -> chunk -> number of TRs to keep) replaces the lookup of
+    `<root>/algonauts_2025.competitors/fmri/<subject>/target_sample_number/<subject>_friends-s7_fmri_samples.npy`; that file
+    is a pickled dict and is only read when `trust_pickle=True` is passed explicitly (a `.json` of the same name is
+    read without it)."""
+
+    def __init__(self, root_data_dir: str | Path | None = None, target_sample_number: dict[str, dict[str, int]] | None = None,
+                 trust_pickle: bool = False) -> None:
+        self.root_data_dir = Path(root_data_dir) if root_data_dir is not None else None
+        self.target_sample_number = target_sample_number
+        self.trust_pickle = trust_pickle
+        self.submission_dict: dict[str, dict[str, tp.Any]] = {}
+
+    def on_test_epoch_start(self, trainer: tp.Any, pl_module: tp.Any) -> None:
+        self.submission_dict = {}
+
+    def on_test_batch_end(self, trainer: tp.Any, pl_module: tp.Any, outputs: tp.Any, batch: tp.Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        y_pred, _ = outputs                                  # no ground truth on the test set
+        if y_pred.is_cuda:
+            rows = ops.transpose_f32(y_pred.float().contiguous()).cpu().numpy()     # [B, T', V], one launch + one copy
+        else:                                                 # BrainModule.test_step already moved them (pl_module.py:107)
+            rows = np.ascontiguousarray(y_pred.float().numpy().transpose(0, 2, 1))
+        overlap_trs = 0   # callbacks.py:56 has 0.0, which makes :73 a TypeError under numpy >= 1.12; the windows do not overlap
+        for i, segment in enumerate(batch.segments):
+            subject = _first_field(segment, "subject").split("/")[1]
+            chunk = "s07" + _first_field(segment, "chunk").split(":")[1]
+            pred = rows[i]
+            per_subject = self.submission_dict.setdefault(subject, {})
+            if chunk not in per_subject:
+                per_subject[chunk] = []
+            else:
+                pred = pred[overlap_trs:]
+            per_subject[chunk].append(pred)
+
+    def _samples(self, subject: str) -> dict[str, int]:
+        if self.target_sample_number is not None:
+            return self.target_sample_number[subject]
+        if self.root_data_dir is None:
+            raise ValueError("Benchmark needs target_sample_number or root_data_dir")
+        base = self.root_data_dir / f"algonauts_2025.competitors/fmri/{subject}/target_sample_number/{subject}_friends-s7_fmri_samples"
+        if base.with_suffix(".json").exists():
+            return {k: int(v) for k, v in json.loads(base.with_suffix(".json").read_text()).items()}
+        if not self.trust_pickle:
+            raise ValueError(f"{base}.npy is a pickled dict; pass trust_pickle=True to read it, or give target_sample_number")
+        return np.load(base.with_suffix(".npy"), allow_pickle=True).item()
+
+    def on_test_epoch_end(self, trainer: tp.Any, pl_module: tp.Any) -> None:
+        for subject in self.submission_dict:
+            for chunk, sample_number in self._samples(subject).items():
+                result = np.concatenate(self.submission_dict[subject][chunk], axis=0)
+                if len(result) < sample_number:
+                    raise ValueError(f"Warning: {len(result)} predictions for {chunk} but expected at least {sample_number}")
+                self.submission_dict[subject][chunk] = result[:sample_number]
+        submission_path = Path(trainer.logger.save_dir) / "submission.npy"
+        np.save(submission_path, self.submission_dict)        # the competition's format: a pickled dict of arrays
+        try:
+            with zipfile.ZipFile(submission_path.with_suffix(".zip"), "w") as zipf:
+                zipf.write(submission_path, arcname=submission_path.name)
+            print(f"Saved submission to {submission_path.with_suffix('.zip')}")
+        except Exception:
+            print(f"Failed to save submission to {submission_path.with_suffix('.zip')}")

@@ -152,6 +152,114 @@ __global__ __launch_bounds__(256) void word_bag_kernel(const float* __restrict__
   }
 }
 
+
+// ---- predictions for the submission writer: out[z][c][r] = in[z][r][c] (f32), 64x64 tiles through LDS ----------------
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int64_t R, int64_t C, float* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int64_t z = blockIdx.z;
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* src = in + z * R * C;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    if (r < R && c < C) tile[i][tx] = src[r * C + c];
+  }
+  __syncthreads();
+  float* dst = out + z * R * C;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) dst[c * R + r] = tile[tx][i];
+  }
+}
+
+// ---- ensemble averaging (grids/average_submissions.py:107-125) -----------------------------------------------------
+// out[i] = sum_n preds[n][i] * w, sequential in n with a separately rounded product and sum (no FMA contraction), which
+// is what numpy's `np.sum(preds * weights, axis=0)` computes:
+//   PER_COLUMN = 1: w = wcol[n * V + i % V], all f32 (per-voxel softmax weights, :96-99);
+//   PER_COLUMN = 0: w = wsub[n] in f64, product and sum in f64, f64 output (score weights, :100-103).
+template <int PER_COLUMN>
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ preds, int64_t N, int64_t M, int64_t V,
+                                                           const float* __restrict__ wcol, const double* __restrict__ wsub,
+                                                           void* __restrict__ out) {
+#pragma clang fp contract(off)   // hipcc contracts a * b + c into an FMA by default; numpy rounds the product first
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    if (PER_COLUMN) {
+      const int64_t v = i % V;
+      float acc = preds[i] * wcol[v];
+      for (int64_t n = 1; n < N; ++n) {
+        const float prod = preds[n * M + i] * wcol[n * V + v];
+        acc = acc + prod;
+      }
+      ((float*)out)[i] = acc;
+    } else {
+      double acc = (double)preds[i] * wsub[0];
+      for (int64_t n = 1; n < N; ++n) {
+        const double prod = (double)preds[n * M + i] * wsub[n];
+        acc = acc + prod;
+      }
+      ((double*)out)[i] = acc;
+    }
+  }
+}
+
+// ---- correlation matrix of N prediction sets (np.corrcoef over rows, average_submissions.py:38-53) ------------------
+// Pass 1: row sums -> means (f64).  Pass 2: every workgroup takes a K slice, accumulates the N x N products of the
+// centred rows in f64 (thread (i, j) owns one pair) and adds its partial to the output with f64 atomics.
+__global__ __launch_bounds__(256) void row_sum_f64_kernel(const float* __restrict__ x, int64_t K, double* __restrict__ sums) {
+  const int64_t n = blockIdx.y;
+  const int64_t per = (K + gridDim.x - 1) / gridDim.x;
+  const int64_t k0 = (int64_t)blockIdx.x * per, k1 = (k0 + per < K) ? k0 + per : K;
+  double acc = 0.0;
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) acc += (double)x[n * K + k];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&sums[n], acc);
+}
+
+constexpr int CORR_MAX_N = 64, CORR_CHUNK = 64;
+__global__ __launch_bounds__(256) void corr_accumulate_kernel(const float* __restrict__ x, int64_t N, int64_t K, const double* __restrict__ sums,
+                                                              double* __restrict__ cov) {
+  __shared__ double tile[CORR_MAX_N][CORR_CHUNK + 1];
+  const int64_t per = ((K + gridDim.x - 1) / gridDim.x + CORR_CHUNK - 1) / CORR_CHUNK * CORR_CHUNK;
+  const int64_t k0 = (int64_t)blockIdx.x * per, k1 = (k0 + per < K) ? k0 + per : K;
+  const int n_pairs = (int)(N * N);
+  double acc[16];                                  // pairs p = threadIdx.x + 256 * q, q < 16  (N <= 64 -> <= 4096 pairs)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+  for (int64_t kc = k0; kc < k1; kc += CORR_CHUNK) {
+    for (int e = threadIdx.x; e < N * CORR_CHUNK; e += 256) {
+      const int n = e / CORR_CHUNK, kk = e % CORR_CHUNK;
+      const int64_t k = kc + kk;
+      tile[n][kk] = (k < k1) ? (double)x[n * K + k] - sums[n] / (double)K : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int p = threadIdx.x + 256 * q;
+      if (p < n_pairs) {
+        const int i = p / (int)N, j = p % (int)N;
+        double a = 0.0;
+        for (int kk = 0; kk < CORR_CHUNK; ++kk) a += tile[i][kk] * tile[j][kk];
+        acc[q] += a;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int p = threadIdx.x + 256 * q;
+    if (p < n_pairs) atomicAdd(&cov[p], acc[q]);
+  }
+}
+
+__global__ void corr_finalize_kernel(const double* __restrict__ cov, int64_t N, double* __restrict__ corr) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N * N) return;
+  const int i = p / (int)N, j = p % (int)N;
+  corr[p] = cov[p] / sqrt(cov[i * N + i] * cov[j * N + j]);
+}
+
 inline unsigned grid_1d(int64_t total, int block) {
   int64_t g = (total + block - 1) / block;
   if (g > 65536 * 16) g = 65536 * 16;
@@ -214,6 +322,52 @@ extern "C" int tribe_word_bag_fwd(const float* table, int64_t n_words, int64_t C
     hipLaunchKernelGGL(word_bag_kernel<4>, dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, (unsigned short*)out, C_pad);
   else
     hipLaunchKernelGGL(word_bag_kernel<1>, dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, (unsigned short*)out, C_pad);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_transpose_f32_fwd(const float* in, int64_t Z, int64_t R, int64_t C, float* out, void* stream) {
+  TRIBE_REQUIRE(in && out && in != out, "tribe_transpose_f32_fwd: null or aliased pointer");
+  TRIBE_REQUIRE(Z > 0 && Z < 65536 && R > 0 && C > 0 && (R + 63) / 64 < 65536, "tribe_transpose_f32_fwd: bad shape Z=%lld R=%lld C=%lld", (long long)Z,
+                (long long)R, (long long)C);
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64), (unsigned)Z);
+  hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, R, C, out);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_weighted_sum_fwd(const float* preds, int64_t N, int64_t M, int64_t V, const float* w_column, const double* w_set,
+                                      void* out, void* stream) {
+  TRIBE_REQUIRE(preds && out, "tribe_weighted_sum_fwd: null pointer");
+  TRIBE_REQUIRE((w_column != nullptr) != (w_set != nullptr), "tribe_weighted_sum_fwd: give exactly one of w_column (f32 [N, V]) / w_set (f64 [N])");
+  TRIBE_REQUIRE(N > 0 && M > 0 && V > 0 && M % V == 0, "tribe_weighted_sum_fwd: bad shape N=%lld M=%lld V=%lld", (long long)N, (long long)M, (long long)V);
+  hipStream_t s = (hipStream_t)stream;
+  if (w_column)
+    hipLaunchKernelGGL(weighted_sum_kernel<1>, dim3(grid_1d(M, 256)), dim3(256), 0, s, preds, N, M, V, w_column, w_set, out);
+  else
+    hipLaunchKernelGGL(weighted_sum_kernel<0>, dim3(grid_1d(M, 256)), dim3(256), 0, s, preds, N, M, V, w_column, w_set, out);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t tribe_corr_matrix_workspace_bytes(int64_t N) { return (size_t)(N + N * N) * sizeof(double); }
+
+extern "C" int tribe_corr_matrix_fwd(const float* x, int64_t N, int64_t K, double* corr, void* workspace, size_t workspace_bytes, void* stream) {
+  TRIBE_REQUIRE(x && corr && workspace, "tribe_corr_matrix_fwd: null pointer");
+  TRIBE_REQUIRE(N > 0 && N <= CORR_MAX_N && K > 1, "tribe_corr_matrix_fwd: N=%lld must be in [1, %d], K=%lld > 1", (long long)N, CORR_MAX_N, (long long)K);
+  TRIBE_REQUIRE(workspace_bytes >= tribe_corr_matrix_workspace_bytes(N), "tribe_corr_matrix_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  double* sums = (double*)workspace;
+  double* cov = sums + N;
+  hipError_t e = hipMemsetAsync(workspace, 0, tribe_corr_matrix_workspace_bytes(N), s);
+  if (e != hipSuccess) { tribe_set_error("tribe_corr_matrix_fwd: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+  int64_t slices = (K + 65535) / 65536;
+  if (slices > 1024) slices = 1024;
+  hipLaunchKernelGGL(row_sum_f64_kernel, dim3((unsigned)slices, (unsigned)N), dim3(256), 0, s, x, K, sums);
+  int64_t blocks = (K + 8191) / 8192;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(corr_accumulate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, N, K, sums, cov);
+  hipLaunchKernelGGL(corr_finalize_kernel, dim3((unsigned)((N * N + 255) / 256)), dim3(256), 0, s, cov, N, corr);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

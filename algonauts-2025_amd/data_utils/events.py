@@ -61,15 +61,8 @@ class Fmri(Event):
     subject: str = ""
 
 
-@dataclasses.dataclass
-class Segment:
-    """A window of one timeline and the events that touch it (segments.py:21-33)."""
-
-    start: float
-    duration: float
-    ns_events: list[tp.Any] = dataclasses.field(default_factory=list)
-    _trigger: tp.Any = None
-
-    @property
-    def stop(self) -> float:
-        return self.start + self.duration
+def __getattr__(name: str) -> tp.Any:   # `Segment` lives in segments.py, as in the reference; kept importable from here
+    if name == "Segment":
+        from .segments import Segment
+        return Segment
+    raise AttributeError(name)

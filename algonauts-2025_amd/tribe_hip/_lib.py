@@ -191,6 +191,10 @@ SIGNATURES = {
     "tribe_group_mean_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, vp, vp]),
     "tribe_segment_gather_fwd": (C.c_int, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),
     "tribe_word_bag_fwd": (C.c_int, [vp, i64, i64, vp, vp, i64, vp, i64, vp]),
+    "tribe_transpose_f32_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
+    "tribe_weighted_sum_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp]),
+    "tribe_corr_matrix_workspace_bytes": (sz, [i64]),
+    "tribe_corr_matrix_fwd": (C.c_int, [vp, i64, i64, vp, vp, sz, vp]),
     "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
     "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),

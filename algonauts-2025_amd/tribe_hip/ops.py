@@ -484,3 +484,51 @@ def word_bag(table: torch.Tensor, row_ptr: torch.Tensor, word_idx: torch.Tensor,
     check(lib().tribe_word_bag_fwd(table.data_ptr(), n_words, C, row_ptr.data_ptr(), word_idx.data_ptr(), rows, out.data_ptr(), C_pad,
                                    _stream()), "tribe_word_bag_fwd")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# after the model: submission rows, ensemble averaging (csrc/features.hip)
+# --------------------------------------------------------------------------------------
+def transpose_f32(x: torch.Tensor) -> torch.Tensor:
+    """f32 [Z, R, C] -> [Z, C, R] (predictions [B, V, T'] -> [B, T', V], callbacks.py:63-64)."""
+    _cuda(x, torch.float32, "x")
+    if x.ndim != 3:
+        raise ValueError(f"transpose_f32: expected [Z, R, C], got {tuple(x.shape)}")
+    Z, R, Cc = x.shape
+    out = torch.empty(Z, Cc, R, dtype=torch.float32, device=x.device)
+    check(lib().tribe_transpose_f32_fwd(x.data_ptr(), Z, R, Cc, out.data_ptr(), _stream()), "tribe_transpose_f32_fwd")
+    return out
+
+
+def weighted_sum(preds: torch.Tensor, w_column: torch.Tensor | None = None, w_set: torch.Tensor | None = None) -> torch.Tensor:
+    """preds f32 [N, ..., V] -> sum over N of preds * w: w_column f32 [N, V] (f32 result) or w_set f64 [N] (f64 result)."""
+    _cuda(preds, torch.float32, "preds")
+    N, V = preds.shape[0], preds.shape[-1]
+    M = preds[0].numel()
+    if (w_column is None) == (w_set is None):
+        raise ValueError("weighted_sum: give exactly one of w_column / w_set")
+    if w_column is not None:
+        _cuda(w_column, torch.float32, "w_column")
+        if tuple(w_column.shape) != (N, V):
+            raise ValueError(f"weighted_sum: w_column {tuple(w_column.shape)} != ({N}, {V})")
+        out = torch.empty(preds.shape[1:], dtype=torch.float32, device=preds.device)
+    else:
+        _cuda(w_set, torch.float64, "w_set")
+        if tuple(w_set.shape) != (N,):
+            raise ValueError(f"weighted_sum: w_set {tuple(w_set.shape)} != ({N},)")
+        out = torch.empty(preds.shape[1:], dtype=torch.float64, device=preds.device)
+    check(lib().tribe_weighted_sum_fwd(preds.data_ptr(), N, M, V, _p(w_column), _p(w_set), out.data_ptr(), _stream()), "tribe_weighted_sum_fwd")
+    return out
+
+
+def corr_matrix(x: torch.Tensor) -> torch.Tensor:
+    """np.corrcoef over the rows of x f32 [N, K] -> f64 [N, N]."""
+    _cuda(x, torch.float32, "x")
+    if x.ndim != 2:
+        raise ValueError(f"corr_matrix: expected [N, K], got {tuple(x.shape)}")
+    N, K = x.shape
+    out = torch.empty(N, N, dtype=torch.float64, device=x.device)
+    nbytes = lib().tribe_corr_matrix_workspace_bytes(N)
+    ws = workspace(nbytes, x.device, tag="corr")
+    check(lib().tribe_corr_matrix_fwd(x.data_ptr(), N, K, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "tribe_corr_matrix_fwd")
+    return out

@@ -427,6 +427,23 @@ int tribe_segment_gather_fwd(const tribe_feature_piece* pieces, const int32_t* s
 int tribe_word_bag_fwd(const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
                        int64_t rows, uint16_t* out, int64_t C_pad, void* stream);
 
+/* ---- steps after the model ------------------------------------------------------------ */
+/* out[z, c, r] = in[z, r, c], f32: predictions [B, V, T'] -> [B, T', V] rows for the submission writer
+ * (`pred = y_pred[i].cpu().numpy().T`, algonauts2025/callbacks.py:63-64), one launch + one D2H copy per batch. */
+int tribe_transpose_f32_fwd(const float* in, int64_t Z, int64_t R, int64_t C, float* out, void* stream);
+/* Ensemble averaging (algonauts2025/grids/average_submissions.py:107-125): out[i] = sum_n preds[n, i] * w, i < M,
+ * sequential in n, product and sum rounded separately (numpy's `np.sum(preds * weights, axis=0)`):
+ *   w_column f32 [N, V] (per-voxel weights, :96-99): w = w_column[n, i % V], f32 arithmetic, out f32 [M];
+ *   w_set    f64 [N]    (score weights,    :100-103): w = w_set[n], f64 arithmetic, out f64 [M].
+ * Exactly one of the two is non-NULL.  The unweighted mean (:121) is tribe_group_mean_fwd with one group [0, N). */
+int tribe_weighted_sum_fwd(const float* preds, int64_t N, int64_t M, int64_t V, const float* w_column, const double* w_set,
+                           void* out, void* stream);
+/* corr f64 [N, N] = np.corrcoef of the N rows of x f32 [N, K] (average_submissions.py:38-53; N <= 64): f64 row means,
+ * f64 products of the centred rows accumulated per K slice and merged with f64 atomics (order not fixed: agreement
+ * with numpy to ~1e-12, not bit-exact). */
+size_t tribe_corr_matrix_workspace_bytes(int64_t N);
+int tribe_corr_matrix_fwd(const float* x, int64_t N, int64_t K, double* corr, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
