@@ -192,6 +192,9 @@ SIGNATURES = {
     "tribe_segment_gather_fwd": (C.c_int, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),
     "tribe_word_bag_fwd": (C.c_int, [vp, i64, i64, vp, vp, i64, vp, i64, vp]),
     "tribe_transpose_f32_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
+    "tribe_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tribe_quantize_fp8_fwd": (C.c_int, [vp, i32, i64, i64, i64, f32, vp, i64, vp]),
+    "tribe_absmax_fwd": (C.c_int, [vp, i32, i64, i64, i64, vp, i32, vp]),
     "tribe_weighted_sum_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp]),
     "tribe_corr_matrix_workspace_bytes": (sz, [i64]),
     "tribe_corr_matrix_fwd": (C.c_int, [vp, i64, i64, vp, vp, sz, vp]),

@@ -532,3 +532,60 @@ def corr_matrix(x: torch.Tensor) -> torch.Tensor:
     ws = workspace(nbytes, x.device, tag="corr")
     check(lib().tribe_corr_matrix_fwd(x.data_ptr(), N, K, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "tribe_corr_matrix_fwd")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# fp8 (e4m3) GEMM + per-tensor quantisation (csrc/gemm_fp8.hip)
+# --------------------------------------------------------------------------------------
+FP8_MAX = 448.0
+
+
+def absmax(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """max |x| of a 2-D f32 / bf16 tensor as a device float (accumulates into `out` when given)."""
+    _cuda(x, (torch.float32, torch.bfloat16), "x")
+    x2 = x.reshape(-1, x.shape[-1])
+    acc = out is not None
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib().tribe_absmax_fwd(x2.data_ptr(), _DT[x.dtype], x2.shape[0], x2.shape[1], x2.shape[1], out.data_ptr(), int(acc), _stream()),
+          "tribe_absmax_fwd")
+    return out
+
+
+def quantize_fp8(x: torch.Tensor, scale: float, K_pad: int | None = None) -> torch.Tensor:
+    """x f32 / bf16 [M, K] -> uint8 [M, K_pad] holding e4m3(clamp(x / scale)); K_pad defaults to K rounded up to 128."""
+    _cuda(x, (torch.float32, torch.bfloat16), "x")
+    if x.ndim != 2 or not scale > 0:
+        raise ValueError(f"quantize_fp8: expected a 2-D tensor and a positive scale, got {tuple(x.shape)}, {scale}")
+    M, K = x.shape
+    K_pad = round_up(K, 128) if K_pad is None else K_pad
+    out = torch.empty(M, K_pad, dtype=torch.uint8, device=x.device)
+    check(lib().tribe_quantize_fp8_fwd(x.data_ptr(), _DT[x.dtype], M, K, K, 1.0 / scale, out.data_ptr(), K_pad, _stream()),
+          "tribe_quantize_fp8_fwd")
+    return out
+
+
+def gemm_fp8_nt(a: torch.Tensor, b: torch.Tensor, alpha: float, *, bias: torch.Tensor | None = None, act: str | None = None,
+                res: torch.Tensor | None = None, out_dtype: torch.dtype = torch.float32, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[m, n] = epi(alpha * sum_k a[m, k] * b[n, k]) with a, b uint8 tensors of e4m3 bytes ([M, K], [N, K], K % 128 == 0)."""
+    _cuda(a, torch.uint8, "a")
+    _cuda(b, torch.uint8, "b")
+    if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError(f"gemm_fp8_nt: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
+    M, K = a.shape
+    N = b.shape[0]
+    n_out = N // 2 if act in ("swiglu", "glu") else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=out_dtype, device=a.device)
+    _cuda(out, (torch.float32, torch.bfloat16), "out")
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, 1, 1
+    d.A, d.lda, d.B, d.ldb = a.data_ptr(), K, b.data_ptr(), K
+    d.C, d.ldc, d.c_dtype, d.alpha = out.data_ptr(), n_out, _DT[out.dtype], alpha
+    if bias is not None:
+        d.bias, d.bias_mode = _cuda(bias, torch.float32, "bias").data_ptr(), _lib.BIAS_COL
+    d.act = {"gelu": _lib.ACT_GELU, "swiglu": _lib.ACT_SWIGLU, "silu": _lib.ACT_SILU, "glu": _lib.ACT_GLU, None: _lib.ACT_NONE}[act]
+    if res is not None:
+        d.res, d.ldres = _cuda(res, torch.float32, "res").data_ptr(), N
+    check(lib().tribe_gemm_fp8(C.byref(d), _stream()), "tribe_gemm_fp8")
+    return out

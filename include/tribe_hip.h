@@ -444,6 +444,19 @@ int tribe_weighted_sum_fwd(const float* preds, int64_t N, int64_t M, int64_t V, 
 size_t tribe_corr_matrix_workspace_bytes(int64_t N);
 int tribe_corr_matrix_fwd(const float* x, int64_t N, int64_t K, double* corr, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fp8 (OCP e4m3) GEMM for the frozen extractors (BASELINE config 5: "fp8 MFMA extractor GEMMs") ----------------
+ * Same descriptor and epilogue as tribe_gemm_bf16 (the nn.Linear calls of transformers' modeling_llama.py /
+ * modeling_vjepa2.py / modeling_wav2vec2_bert.py), but A [M, K] and B [N, K] hold e4m3 bytes (K contiguous; lda / ldb /
+ * batch strides in elements = bytes, multiples of 16; K a multiple of 128) and `alpha` carries scale_A * scale_B of the
+ * per-tensor quantisation.  v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, f32 accumulation. */
+int tribe_gemm_fp8(const tribe_gemm_desc* d, void* stream);
+/* out[m, k] = e4m3(clamp(x[m, k] * inv_scale, -448, 448)) (round to nearest even), x f32 | bf16 [M, K] with row stride ld,
+ * out [M, K_pad] bytes, columns K..K_pad zero; K_pad a multiple of 16. */
+int tribe_quantize_fp8_fwd(const void* x, int32_t x_dtype, int64_t M, int64_t K, int64_t ld, float inv_scale, uint8_t* out,
+                           int64_t K_pad, void* stream);
+/* out[0] = max(out[0] if accumulate else 0, max |x|)  (device float; calibration of the per-tensor scales) */
+int tribe_absmax_fwd(const void* x, int32_t x_dtype, int64_t M, int64_t K, int64_t ld, float* out, int32_t accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
