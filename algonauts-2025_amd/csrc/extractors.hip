@@ -23,7 +23,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct LlamaPlan {
   int64_t M, qkv_w, q_w;
-  size_t x_b, xn_b, qkv_b, ao_b, act_b, fin_b;
+  size_t x_b, xn_b, qkv_b, ao_b, act_b, fin_b, q8_b;
 };
 inline LlamaPlan llama_plan(const tribe_llama_desc* d) {
   LlamaPlan p;
@@ -36,14 +36,47 @@ inline LlamaPlan llama_plan(const tribe_llama_desc* d) {
   p.ao_b = align256((size_t)p.M * p.q_w * 2);
   p.act_b = align256((size_t)p.M * d->inter * 2);
   p.fin_b = align256((size_t)p.M * d->dim * 4);
+  const int64_t widest = d->inter > p.q_w ? (d->inter > d->dim ? d->inter : d->dim) : (p.q_w > d->dim ? p.q_w : d->dim);
+  p.q8_b = d->fp8_host ? align256((size_t)p.M * widest) : 0;   // one e4m3 staging buffer: every quantised input is consumed at once
   return p;
+}
+
+// one Linear of an extractor layer: bf16 GEMM, or quantise the bf16 input with its static scale and run the e4m3 GEMM.
+// `amax` (calibration, bf16 path only) and the fp8 fields come from the layer's descriptor; tribe_llama_fp8_layer and
+// tribe_vit_fp8_layer share this layout: four weight pointers, four weight scales, four input scales.
+struct Fp8Linear4 {
+  const uint8_t* w[4];
+  float w_scale[4];
+  float in_scale[4];
+};
+static_assert(sizeof(Fp8Linear4) == sizeof(tribe_llama_fp8_layer) && sizeof(Fp8Linear4) == sizeof(tribe_vit_fp8_layer), "fp8 layer layouts");
+
+inline int extractor_linear(const char* who, const void* fp8_layers, float* amax_out, int layer, int which, tribe_gemm_desc& g,
+                            const void* w_bf16, uint8_t* q8, void* stream) {
+  if (amax_out) {
+    int rc = tribe_absmax_fwd(g.A, TRIBE_BF16, g.M, g.K, g.lda, amax_out + (int64_t)layer * 4 + which, 1, stream);
+    if (rc) return rc;
+  }
+  if (!fp8_layers) {
+    g.B = w_bf16;
+    return tribe_gemm_bf16(&g, stream);
+  }
+  const Fp8Linear4& F = ((const Fp8Linear4*)fp8_layers)[layer];
+  TRIBE_REQUIRE(F.w[which] && F.in_scale[which] > 0.f && F.w_scale[which] > 0.f, "%s: layer %d fp8 weight %d or its scales missing", who, layer,
+                which);
+  int rc = tribe_quantize_fp8_fwd(g.A, TRIBE_BF16, g.M, g.K, g.lda, 1.0f / F.in_scale[which], q8, g.K, stream);
+  if (rc) return rc;
+  g.A = q8;
+  g.B = F.w[which];
+  g.alpha = F.in_scale[which] * F.w_scale[which];
+  return tribe_gemm_fp8(&g, stream);
 }
 }  // namespace
 
 extern "C" size_t tribe_llama_workspace_bytes(const tribe_llama_desc* d) {
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   const LlamaPlan p = llama_plan(d);
-  return p.x_b + p.xn_b + p.qkv_b + p.ao_b + p.act_b + p.fin_b;
+  return p.x_b + p.xn_b + p.qkv_b + p.ao_b + p.act_b + p.fin_b + p.q8_b;
 }
 
 extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream) {
@@ -64,8 +97,12 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
   uint16_t* qkv = (uint16_t*)w; w += p.qkv_b;
   uint16_t* ao = (uint16_t*)w; w += p.ao_b;
   uint16_t* act = (uint16_t*)w; w += p.act_b;
-  float* fin = (float*)w;
+  float* fin = (float*)w; w += p.fin_b;
+  uint8_t* q8 = (uint8_t*)w;
   const int64_t M = p.M, dim = d->dim, BD = d->B * dim;
+  TRIBE_REQUIRE(!d->fp8_host || (d->dim % 128 == 0 && p.q_w % 128 == 0 && d->inter % 128 == 0),
+                "tribe_llama_fwd: the fp8 path needs dim, heads_q * dim_head and inter to be multiples of 128");
+  TRIBE_REQUIRE(!(d->fp8_host && d->amax_out), "tribe_llama_fwd: calibrate (amax_out) on the bf16 path, not together with fp8_host");
 
   int rc = tribe_embedding_fwd(d->embed, d->embed_dtype, d->ids, M, dim, d->vocab, x, stream);
   if (rc) return rc;
@@ -80,9 +117,9 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
     if (rc) return rc;
     tribe_gemm_desc g = gemm_zero();
     g.M = M; g.N = p.qkv_w; g.K = dim;
-    g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
+    g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = qkv; g.ldc = p.qkv_w; g.c_dtype = TRIBE_BF16; g.role = TRIBE_ROLE_QKV;
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 0, g, L.w_qkv, q8, stream);
     if (rc) return rc;
     // rotate_half rotary over the full head dim on the q heads and the k heads (adjacent in the fused row)
     rc = tribe_rotary_fwd(qkv, M, d->T, p.qkv_w, d->heads_q + d->heads_kv, d->dim_head, d->dim_head, d->cos_tab, d->sin_tab, 0, stream);
@@ -99,23 +136,23 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = dim; g.K = p.q_w;
-    g.A = ao; g.lda = p.q_w; g.B = L.w_o; g.ldb = p.q_w;
+    g.A = ao; g.lda = p.q_w; g.ldb = p.q_w;
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_OUT_PROJ;
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 1, g, L.w_o, q8, stream);
     if (rc) return rc;
     rc = tribe_rmsnorm_fwd(x, M, dim, L.post_norm_w, d->rms_eps, xn, TRIBE_BF16, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = 2 * (int64_t)d->inter; g.K = dim;
-    g.A = xn; g.lda = dim; g.B = L.w_gate_up; g.ldb = dim;
+    g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = act; g.ldc = d->inter; g.c_dtype = TRIBE_BF16; g.act = TRIBE_ACT_SWIGLU; g.role = TRIBE_ROLE_FF1;
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 2, g, L.w_gate_up, q8, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = dim; g.K = d->inter;
-    g.A = act; g.lda = d->inter; g.B = L.w_down; g.ldb = d->inter;
+    g.A = act; g.lda = d->inter; g.ldb = d->inter;
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_FF2;
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 3, g, L.w_down, q8, stream);
     if (rc) return rc;
     if (l + 1 < d->depth) {
       rc = tribe_segment_mean_fwd(x, d->B, d->T, dim, d->pool_start, d->pool_len, states + (int64_t)(l + 1) * BD, dim, stream);
@@ -140,7 +177,7 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
 namespace {
 struct VitPlan {
   int64_t tokens, M;
-  size_t x_b, xn_b, qkv_b, ao_b, act_b, col_b;
+  size_t x_b, xn_b, qkv_b, ao_b, act_b, col_b, q8_b;
 };
 inline VitPlan vit_plan(const tribe_vjepa2_desc* d) {
   VitPlan p;
@@ -152,6 +189,7 @@ inline VitPlan vit_plan(const tribe_vjepa2_desc* d) {
   p.ao_b = align256((size_t)p.M * d->dim * 2);
   p.act_b = align256((size_t)p.M * d->mlp * 2);
   p.col_b = align256((size_t)p.M * d->K_pad * 2);
+  p.q8_b = d->fp8_host ? align256((size_t)p.M * (d->mlp > d->dim ? d->mlp : d->dim)) : 0;
   return p;
 }
 }  // namespace
@@ -160,7 +198,7 @@ extern "C" size_t tribe_vjepa2_workspace_bytes(const tribe_vjepa2_desc* d) {
   if (!d || d->B <= 0 || d->tubelet <= 0 || d->patch <= 0) return 0;
   const VitPlan p = vit_plan(d);
   const size_t tail = p.act_b > p.col_b ? p.act_b : p.col_b;  // the im2col buffer is dead once the embedding GEMM ran
-  return p.x_b + p.xn_b + p.qkv_b + p.ao_b + tail;
+  return p.x_b + p.xn_b + p.qkv_b + p.ao_b + tail + p.q8_b;
 }
 
 extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream) {
@@ -180,7 +218,10 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
   uint16_t* ao = (uint16_t*)w; w += p.ao_b;
   uint16_t* act = (uint16_t*)w;
   uint16_t* col = (uint16_t*)w;
+  uint8_t* q8 = (uint8_t*)(w + (p.act_b > p.col_b ? p.act_b : p.col_b));
   const int64_t M = p.M, dim = d->dim, BD = d->B * dim;
+  TRIBE_REQUIRE(!d->fp8_host || (d->dim % 128 == 0 && d->mlp % 128 == 0), "tribe_vjepa2_fwd: the fp8 path needs dim and mlp to be multiples of 128");
+  TRIBE_REQUIRE(!(d->fp8_host && d->amax_out), "tribe_vjepa2_fwd: calibrate (amax_out) on the bf16 path, not together with fp8_host");
 
   int rc = tribe_im2col3d_fwd(d->pixels, d->B, d->frames, d->chans, d->height, d->width, d->tubelet, d->patch, col, d->K_pad, stream);
   if (rc) return rc;
@@ -201,10 +242,10 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = 3 * dim; g.K = dim;
-    g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
+    g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = qkv; g.ldc = 3 * dim; g.c_dtype = TRIBE_BF16; g.role = TRIBE_ROLE_QKV;
     if (L.b_qkv) { g.bias = L.b_qkv; g.bias_mode = TRIBE_BIAS_COL; }
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 0, g, L.w_qkv, q8, stream);
     if (rc) return rc;
     rc = tribe_rotary_fwd(qkv, M, p.tokens, 3 * dim, 2 * d->heads, d->dim_head, d->dim_head, d->cos_tab, d->sin_tab, 2, stream);
     if (rc) return rc;
@@ -219,26 +260,26 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = dim; g.K = dim;
-    g.A = ao; g.lda = dim; g.B = L.w_proj; g.ldb = dim;
+    g.A = ao; g.lda = dim; g.ldb = dim;
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_OUT_PROJ;
     if (L.b_proj) { g.bias = L.b_proj; g.bias_mode = TRIBE_BIAS_COL; }
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 1, g, L.w_proj, q8, stream);
     if (rc) return rc;
     rc = tribe_layernorm_fwd(x, M, dim, L.norm2_w, L.norm2_b, d->ln_eps, xn, TRIBE_BF16, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = d->mlp; g.K = dim;
-    g.A = xn; g.lda = dim; g.B = L.w_fc1; g.ldb = dim;
+    g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = act; g.ldc = d->mlp; g.c_dtype = TRIBE_BF16; g.act = TRIBE_ACT_GELU; g.role = TRIBE_ROLE_FF1;
     if (L.b_fc1) { g.bias = L.b_fc1; g.bias_mode = TRIBE_BIAS_COL; }
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 2, g, L.w_fc1, q8, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = dim; g.K = d->mlp;
-    g.A = act; g.lda = d->mlp; g.B = L.w_fc2; g.ldb = d->mlp;
+    g.A = act; g.lda = d->mlp; g.ldb = d->mlp;
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_FF2;
     if (L.b_fc2) { g.bias = L.b_fc2; g.bias_mode = TRIBE_BIAS_COL; }
-    rc = tribe_gemm_bf16(&g, stream);
+    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 3, g, L.w_fc2, q8, stream);
     if (rc) return rc;
     rc = tribe_segment_mean_fwd(x, d->B, p.tokens, dim, nullptr, nullptr, states + (int64_t)(l + 1) * BD, dim, stream);
     if (rc) return rc;

@@ -93,18 +93,20 @@ class HipLlamaModel:
 
         self.embed = f32("embed_tokens.weight").to(torch.bfloat16).contiguous()  # bf16 table: 0.79 GB for the 3B vocab
         self.layers = (LlamaLayer * max(self.depth, 1))()
+        self.packs: list[tuple[torch.Tensor, ...]] = []      # bf16 (qkv, o, gate_up, down) per layer, the source of the fp8 packs
+        self.fp8_layers = None                               # LlamaFp8Layer array once enable_fp8() has run
         for i in range(self.depth):
             p = f"layers.{i}."
             L = self.layers[i]
             wqkv = torch.cat([f32(p + "self_attn.q_proj.weight"), f32(p + "self_attn.k_proj.weight"), f32(p + "self_attn.v_proj.weight")])
             gate, up = f32(p + "mlp.gate_proj.weight"), f32(p + "mlp.up_proj.weight")
             gate_up = torch.stack([gate, up], dim=1).reshape(2 * self.inter, self.dim).contiguous()  # rows: g0, u0, g1, u1, ...
+            packs = (ops.pack_weight(wqkv), ops.pack_weight(f32(p + "self_attn.o_proj.weight")), ops.pack_weight(gate_up),
+                     ops.pack_weight(f32(p + "mlp.down_proj.weight")))
+            self.packs.append(packs)
             L.input_norm_w = own(f32(p + "input_layernorm.weight"))
-            L.w_qkv = own(ops.pack_weight(wqkv))
-            L.w_o = own(ops.pack_weight(f32(p + "self_attn.o_proj.weight")))
+            L.w_qkv, L.w_o, L.w_gate_up, L.w_down = (t.data_ptr() for t in packs)
             L.post_norm_w = own(f32(p + "post_attention_layernorm.weight"))
-            L.w_gate_up = own(ops.pack_weight(gate_up))
-            L.w_down = own(ops.pack_weight(f32(p + "mlp.down_proj.weight")))
             del wqkv, gate, up, gate_up
         self.final_norm = f32("norm.weight")
         self._tabs: dict[int, tuple[torch.Tensor, torch.Tensor]] = {}
@@ -115,9 +117,38 @@ class HipLlamaModel:
             self._tabs[T] = (freqs.cos().to(self.device).contiguous(), freqs.sin().to(self.device).contiguous())
         return self._tabs[T]
 
-    def forward_pooled(self, input_ids: torch.Tensor, pool_start: torch.Tensor, pool_len: torch.Tensor) -> torch.Tensor:
+    def enable_fp8(self, calibration_ids: torch.Tensor, margin: float = 1.0) -> torch.Tensor:
+        """Switch the four Linear GEMMs of every layer to e4m3 (BASELINE config 5): per-tensor weight scales amax / 448 and
+        static per-tensor input scales from one bf16 calibration pass over `calibration_ids` [B, T] (amax * margin / 448).
+        Returns the calibration amax table f32 [depth, 4] (qkv in, o_proj in, gate_up in, down in)."""
+        if any(v % 128 for v in (self.dim, self.heads_q * self.dim_head, self.inter)):
+            raise ValueError("fp8 path: hidden_size, num_attention_heads * head_dim and intermediate_size must be multiples of 128")
+        self.fp8_layers = None
+        amax = torch.zeros(max(self.depth, 1), 4, dtype=torch.float32, device=self.device)
+        B, T = calibration_ids.shape
+        zeros, full = torch.zeros(B, dtype=torch.int64), torch.full((B,), T, dtype=torch.int64)
+        self.forward_pooled(calibration_ids, zeros, full, _amax=amax)
+        table = amax.cpu()                                    # one-time sync: the scales become launch constants
+        if not bool((table[: self.depth] > 0).all()):
+            raise ValueError("fp8 calibration saw an all-zero GEMM input")
+        layers = (_lib.LlamaFp8Layer * max(self.depth, 1))()
+        self.fp8_packs = []
+        for i in range(self.depth):
+            q = []
+            for j, w in enumerate(self.packs[i]):
+                w_scale = float(ops.absmax(w)) / ops.FP8_MAX
+                q.append(ops.quantize_fp8(w, w_scale, K_pad=w.shape[1]))
+                layers[i].w_scale[j] = w_scale
+                layers[i].in_scale[j] = float(table[i, j]) * margin / ops.FP8_MAX
+            layers[i].w_qkv, layers[i].w_o, layers[i].w_gate_up, layers[i].w_down = (t.data_ptr() for t in q)
+            self.fp8_packs.append(q)
+        self.fp8_layers = layers
+        return table
+
+    def forward_pooled(self, input_ids: torch.Tensor, pool_start: torch.Tensor, pool_len: torch.Tensor, fp8: bool | None = None,
+                       _amax: torch.Tensor | None = None) -> torch.Tensor:
         """input_ids int64 [B, T] (right padded); returns f32 [n_layers + 1, B, dim]: every hidden state averaged over
-        positions [pool_start[b], pool_start[b] + pool_len[b])."""
+        positions [pool_start[b], pool_start[b] + pool_len[b]).  fp8: None = use the e4m3 GEMMs when enable_fp8() has run."""
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         B, T = ids.shape
         if int(ids.min()) < 0 or int(ids.max()) >= self.vocab:
@@ -134,6 +165,13 @@ class HipLlamaModel:
         d.final_norm_w = self.final_norm.data_ptr()
         d.cos_tab, d.sin_tab = cos.data_ptr(), sin.data_ptr()
         d.ids, d.pool_start, d.pool_len = ids.data_ptr(), start.data_ptr(), length.data_ptr()
+        use_fp8 = (self.fp8_layers is not None) if fp8 is None else fp8
+        if use_fp8 and _amax is None:
+            if self.fp8_layers is None:
+                raise ValueError("forward_pooled(fp8=True) before enable_fp8()")
+            d.fp8_host = C.cast(self.fp8_layers, C.POINTER(_lib.LlamaFp8Layer))
+        if _amax is not None:
+            d.amax_out = _amax.data_ptr()
         states = torch.empty(self.depth + 1, B, self.dim, dtype=torch.float32, device=self.device)
         ws = ops.workspace(lib().tribe_llama_workspace_bytes(C.byref(d)), self.device, "extractor")
         check(lib().tribe_llama_fwd(C.byref(d), states.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),

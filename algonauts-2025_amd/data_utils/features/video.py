@@ -71,22 +71,54 @@ class HipVJEPA2Encoder:
         self.w_patch = ops.pack_weight(wp.reshape(self.dim, -1).contiguous())
         self.b_patch = f32("embeddings.patch_embeddings.proj.bias")
         self.layers = (VitLayer * max(self.depth, 1))()
+        self.packs: list[tuple[torch.Tensor, ...]] = []      # bf16 (qkv, proj, fc1, fc2) per layer, the source of the fp8 packs
+        self.fp8_layers = None                               # VitFp8Layer array once enable_fp8() has run
         for i in range(self.depth):
             p = f"layer.{i}."
             L = self.layers[i]
             wqkv = torch.cat([f32(p + "attention.query.weight"), f32(p + "attention.key.weight"), f32(p + "attention.value.weight")])
             bq = f32(p + "attention.query.bias")
             L.norm1_w, L.norm1_b = own(f32(p + "norm1.weight")), own(f32(p + "norm1.bias"))
-            L.w_qkv = own(ops.pack_weight(wqkv))
+            packs = (ops.pack_weight(wqkv), ops.pack_weight(f32(p + "attention.proj.weight")), ops.pack_weight(f32(p + "mlp.fc1.weight")),
+                     ops.pack_weight(f32(p + "mlp.fc2.weight")))
+            self.packs.append(packs)
+            L.w_qkv, L.w_proj, L.w_fc1, L.w_fc2 = (own(t) for t in packs)
             L.b_qkv = own(torch.cat([bq, f32(p + "attention.key.bias"), f32(p + "attention.value.bias")])) if bq is not None else None
-            L.w_proj, L.b_proj = own(ops.pack_weight(f32(p + "attention.proj.weight"))), own(f32(p + "attention.proj.bias"))
+            L.b_proj = own(f32(p + "attention.proj.bias"))
             L.norm2_w, L.norm2_b = own(f32(p + "norm2.weight")), own(f32(p + "norm2.bias"))
-            L.w_fc1, L.b_fc1 = own(ops.pack_weight(f32(p + "mlp.fc1.weight"))), own(f32(p + "mlp.fc1.bias"))
-            L.w_fc2, L.b_fc2 = own(ops.pack_weight(f32(p + "mlp.fc2.weight"))), own(f32(p + "mlp.fc2.bias"))
+            L.b_fc1, L.b_fc2 = own(f32(p + "mlp.fc1.bias")), own(f32(p + "mlp.fc2.bias"))
         self._tabs: dict[tuple[int, int], tuple[torch.Tensor, torch.Tensor]] = {}
 
-    def hidden_state_means(self, pixel_values_videos: torch.Tensor) -> torch.Tensor:
-        """pixel_values_videos f32 [B, frames, C, H, W] -> f32 [B, depth + 1, dim] (video.py:262-268 + :228)."""
+    def enable_fp8(self, calibration_clip: torch.Tensor, margin: float = 1.0) -> torch.Tensor:
+        """e4m3 Linear GEMMs (BASELINE config 5), as HipLlamaModel.enable_fp8: per-tensor weight scales, static input scales
+        from one bf16 pass over `calibration_clip` [B, frames, C, H, W].  Returns the amax table f32 [depth, 4]."""
+        from tribe_hip._lib import VitFp8Layer
+
+        if self.dim % 128 or self.mlp % 128:
+            raise ValueError("fp8 path: hidden_size and the MLP width must be multiples of 128")
+        self.fp8_layers = None
+        amax = torch.zeros(max(self.depth, 1), 4, dtype=torch.float32, device=self.device)
+        self.hidden_state_means(calibration_clip, _amax=amax)
+        table = amax.cpu()
+        if not bool((table[: self.depth] > 0).all()):
+            raise ValueError("fp8 calibration saw an all-zero GEMM input")
+        layers = (VitFp8Layer * max(self.depth, 1))()
+        self.fp8_packs = []
+        for i in range(self.depth):
+            q = []
+            for j, w in enumerate(self.packs[i]):
+                w_scale = float(ops.absmax(w)) / ops.FP8_MAX
+                q.append(ops.quantize_fp8(w, w_scale, K_pad=w.shape[1]))
+                layers[i].w_scale[j] = w_scale
+                layers[i].in_scale[j] = float(table[i, j]) * margin / ops.FP8_MAX
+            layers[i].w_qkv, layers[i].w_proj, layers[i].w_fc1, layers[i].w_fc2 = (t.data_ptr() for t in q)
+            self.fp8_packs.append(q)
+        self.fp8_layers = layers
+        return table
+
+    def hidden_state_means(self, pixel_values_videos: torch.Tensor, fp8: bool | None = None, _amax: torch.Tensor | None = None) -> torch.Tensor:
+        """pixel_values_videos f32 [B, frames, C, H, W] -> f32 [B, depth + 1, dim] (video.py:262-268 + :228).
+        fp8: None = use the e4m3 GEMMs when enable_fp8() has run."""
         pix = pixel_values_videos.to(device=self.device, dtype=torch.float32).contiguous()
         B, F, Cc, H, W = pix.shape
         if Cc != self.chans or F % self.tubelet or H % self.patch or W % self.patch:
@@ -104,6 +136,13 @@ class HipVJEPA2Encoder:
         d.w_patch, d.b_patch, d.K_pad = self.w_patch.data_ptr(), ops._p(self.b_patch), self.w_patch.shape[1]
         d.layers_host = C.cast(self.layers, C.POINTER(VitLayer))
         d.cos_tab, d.sin_tab, d.pixels = cos.data_ptr(), sin.data_ptr(), pix.data_ptr()
+        use_fp8 = (self.fp8_layers is not None) if fp8 is None else fp8
+        if use_fp8 and _amax is None:
+            if self.fp8_layers is None:
+                raise ValueError("hidden_state_means(fp8=True) before enable_fp8()")
+            d.fp8_host = C.cast(self.fp8_layers, C.POINTER(type(self.fp8_layers[0])))
+        if _amax is not None:
+            d.amax_out = _amax.data_ptr()
         states = torch.empty(self.depth + 1, B, self.dim, dtype=torch.float32, device=self.device)
         ws = ops.workspace(lib().tribe_vjepa2_workspace_bytes(C.byref(d)), self.device, "extractor")
         check(lib().tribe_vjepa2_fwd(C.byref(d), states.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),

@@ -68,6 +68,12 @@ class LlamaLayer(C.Structure):
     _fields_ = [("input_norm_w", vp), ("w_qkv", vp), ("w_o", vp), ("post_norm_w", vp), ("w_gate_up", vp), ("w_down", vp)]
 
 
+class LlamaFp8Layer(C.Structure):
+    """struct tribe_llama_fp8_layer"""
+
+    _fields_ = [("w_qkv", vp), ("w_o", vp), ("w_gate_up", vp), ("w_down", vp), ("w_scale", f32 * 4), ("in_scale", f32 * 4)]
+
+
 class LlamaDesc(C.Structure):
     """struct tribe_llama_desc"""
 
@@ -79,6 +85,7 @@ class LlamaDesc(C.Structure):
         ("layers_host", C.POINTER(LlamaLayer)),
         ("final_norm_w", vp), ("cos_tab", vp), ("sin_tab", vp),
         ("ids", vp), ("pool_start", vp), ("pool_len", vp),
+        ("fp8_host", C.POINTER(LlamaFp8Layer)), ("amax_out", vp),
     ]
 
 
@@ -87,6 +94,12 @@ class VitLayer(C.Structure):
 
     _fields_ = [(n, vp) for n in ("norm1_w", "norm1_b", "w_qkv", "b_qkv", "w_proj", "b_proj", "norm2_w", "norm2_b", "w_fc1", "b_fc1",
                                   "w_fc2", "b_fc2")]
+
+
+class VitFp8Layer(C.Structure):
+    """struct tribe_vit_fp8_layer"""
+
+    _fields_ = [("w_qkv", vp), ("w_proj", vp), ("w_fc1", vp), ("w_fc2", vp), ("w_scale", f32 * 4), ("in_scale", f32 * 4)]
 
 
 class Vjepa2Desc(C.Structure):
@@ -100,6 +113,7 @@ class Vjepa2Desc(C.Structure):
         ("w_patch", vp), ("b_patch", vp), ("K_pad", i64),
         ("layers_host", C.POINTER(VitLayer)),
         ("cos_tab", vp), ("sin_tab", vp), ("pixels", vp),
+        ("fp8_host", C.POINTER(VitFp8Layer)), ("amax_out", vp),
     ]
 
 

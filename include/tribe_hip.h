@@ -225,6 +225,13 @@ typedef struct tribe_vit_layer {
   const uint16_t* w_fc2; const float* b_fc2;   /* bf16 [dim, mlp] */
 } tribe_vit_layer;
 
+/* fp8 variant of a ViT layer's four Linear weights (see tribe_llama_fp8_layer): i = 0 qkv, 1 proj, 2 fc1, 3 fc2 */
+typedef struct tribe_vit_fp8_layer {
+  const uint8_t* w_qkv; const uint8_t* w_proj; const uint8_t* w_fc1; const uint8_t* w_fc2;
+  float w_scale[4];
+  float in_scale[4];
+} tribe_vit_fp8_layer;
+
 typedef struct tribe_vjepa2_desc {
   int64_t B;                                   /* clips */
   int32_t frames, chans, height, width, tubelet, patch;
@@ -234,6 +241,8 @@ typedef struct tribe_vjepa2_desc {
   const tribe_vit_layer* layers_host;          /* HOST array [depth] */
   const float* cos_tab; const float* sin_tab;  /* f32 [tokens, dim_head] per-element 3-D rope tables */
   const float* pixels;                         /* f32 [B, frames, chans, H, W] (output of the HF video processor) */
+  const tribe_vit_fp8_layer* fp8_host;         /* HOST array [depth] or NULL: e4m3 GEMMs (dim and mlp multiples of 128) */
+  float* amax_out;                             /* device f32 [depth, 4] or NULL: calibration of the bf16 path (max-accumulated) */
 } tribe_vjepa2_desc;
 
 size_t tribe_vjepa2_workspace_bytes(const tribe_vjepa2_desc* d);
@@ -294,6 +303,15 @@ typedef struct tribe_llama_layer {
   const uint16_t* w_down;        /* bf16 [dim, inter] */
 } tribe_llama_layer;
 
+/* fp8 variant of a layer's four Linear weights (BASELINE config 5): e4m3 bytes in the same row order as the bf16 packs,
+ * per-tensor scales w_scale[i] (weight = byte value * scale) and static per-tensor input scales in_scale[i] for the
+ * four GEMM inputs, i = 0 qkv (normed x), 1 o_proj (attention output), 2 gate_up (normed x), 3 down (SwiGLU output). */
+typedef struct tribe_llama_fp8_layer {
+  const uint8_t* w_qkv; const uint8_t* w_o; const uint8_t* w_gate_up; const uint8_t* w_down;
+  float w_scale[4];
+  float in_scale[4];
+} tribe_llama_fp8_layer;
+
 typedef struct tribe_llama_desc {
   int64_t B, T;                  /* right-padded batch of token ids */
   int32_t dim, depth, heads_q, heads_kv, dim_head, inter;
@@ -304,6 +322,10 @@ typedef struct tribe_llama_desc {
   const float* cos_tab; const float* sin_tab;   /* f32 [T, dim_head/2] (rope scaling already applied) */
   const int64_t* ids;            /* [B*T] */
   const int64_t* pool_start; const int64_t* pool_len;  /* [B] token window averaged per hidden state */
+  const tribe_llama_fp8_layer* fp8_host;  /* HOST array [depth] or NULL: run the four Linear GEMMs of every layer in fp8
+                                             (needs dim, heads_q * dim_head and inter to be multiples of 128) */
+  float* amax_out;               /* device f32 [depth, 4] or NULL: max |input| of the four GEMMs per layer (calibration run
+                                    of the bf16 path; accumulated with max, zero it first) */
 } tribe_llama_desc;
 
 size_t tribe_llama_workspace_bytes(const tribe_llama_desc* d);

@@ -48,6 +48,17 @@ def bench_llama():
         per_tok = L * (2 * H * (hq + 2 * hkv) * dh + 2 * hq * dh * H + 2 * 3 * H * I + 4 * (T / 2) * hq * dh)  # causal: T/2 keys on average
         print(f"llama-3.2-3B fwd+pool  B={B} T={T}: {dt * 1e3:8.2f} ms  {B * T / dt:10.0f} tok/s  {B / dt:7.1f} words/s  "
               f"{per_tok * B * T / dt / 1e12:7.1f} TFLOP/s", flush=True)
+    ref = model.forward_pooled(ids, start, length)
+    model.enable_fp8(torch.randint(0, vocab, (4, 1024), generator=g))           # e4m3 Linear GEMMs, static per-tensor scales
+    for B, T in ((8, 1024), (32, 1024)):
+        ids8 = torch.randint(0, vocab, (B, T), generator=g)
+        start, length = torch.full((B,), T - 5), torch.full((B,), 5)
+        dt = timed(lambda: model.forward_pooled(ids8, start, length))
+        print(f"llama-3.2-3B fwd+pool  B={B} T={T} fp8 GEMMs: {dt * 1e3:8.2f} ms  {B * T / dt:10.0f} tok/s  {B / dt:7.1f} words/s  "
+              f"{per_tok * B * T / dt / 1e12:7.1f} TFLOP/s", flush=True)
+    got = model.forward_pooled(ids, start, length)
+    err = ((got - ref).norm(dim=-1) / ref.norm(dim=-1)).mean(dim=1)
+    print("  fp8 vs bf16 pooled states, mean relative L2 error at layers 1 / 14 / 28:", [round(float(err[i]), 4) for i in (1, 14, 28)], flush=True)
 
 
 def _rand_sd(hf_cls, cfg_cls, kwargs):
@@ -83,6 +94,16 @@ def bench_vjepa2():
         dt = timed(lambda: enc.hidden_state_means(clips), n=3, warm=1)
         print(f"vjepa2-vitg fwd+mean  clips={B} (8192 tokens each): {dt * 1e3:8.2f} ms  {B / dt:6.2f} clips/s  "
               f"{per_tok * B * tok / dt / 1e12:7.1f} TFLOP/s", flush=True)
+    ref = enc.hidden_state_means(clips)
+    enc.enable_fp8(torch.randn(1, 64, 3, 256, 256, device="cuda"))
+    for B in (1, 2):
+        clips8 = torch.randn(B, 64, 3, 256, 256, device="cuda")
+        dt = timed(lambda: enc.hidden_state_means(clips8), n=3, warm=1)
+        print(f"vjepa2-vitg fwd+mean  clips={B} fp8 GEMMs: {dt * 1e3:8.2f} ms  {B / dt:6.2f} clips/s  "
+              f"{per_tok * B * tok / dt / 1e12:7.1f} TFLOP/s", flush=True)
+    got = enc.hidden_state_means(clips)
+    err = ((got - ref).norm(dim=-1) / ref.norm(dim=-1)).mean(dim=0)
+    print("  fp8 vs bf16 token means, relative L2 error at layers 1 / 20 / 40:", [round(float(err[i]), 4) for i in (1, 20, 40)], flush=True)
 
 
 def bench_w2vbert():
