@@ -211,6 +211,44 @@ inline unsigned grid_for(int64_t total, int block) {
   return (unsigned)b;
 }
 
+
+// ---- Adam over a whole parameter group in ONE launch (torch.optim.Adam semantics, defaults.py:126-133) -----------------
+// table[i] = {p, g, m, v, n}; work is cut into chunks of ADAM_CHUNK elements: chunk c belongs to tensor chunk_tensor[c] and
+// starts at element chunk_start[c].  HBM-bound: 16 B read + 12 B written per parameter.
+constexpr int ADAM_CHUNK = 16384;
+__global__ __launch_bounds__(256) void adam_step_kernel(const tribe_adam_tensor* __restrict__ table, const int32_t* __restrict__ chunk_tensor,
+                                                        const int64_t* __restrict__ chunk_start, float lr, float beta1, float beta2, float eps,
+                                                        float weight_decay, float bias_c1, float bias_c2_sqrt, int decoupled) {
+  const tribe_adam_tensor t = table[chunk_tensor[blockIdx.x]];
+  const int64_t i0 = chunk_start[blockIdx.x];
+  const int64_t i1 = (i0 + ADAM_CHUNK < t.n) ? i0 + ADAM_CHUNK : t.n;
+  const float step_size = lr / bias_c1;
+  const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0 && (i0 & 3) == 0;
+  auto update = [&](float& p, float g, float& m, float& v) {
+    if (weight_decay != 0.f) {
+      if (decoupled) p *= 1.f - lr * weight_decay;           // AdamW
+      else g = fmaf(weight_decay, p, g);                      // Adam: L2 term joins the gradient
+    }
+    m = fmaf(1.f - beta1, g - m, m);                          // exp_avg.lerp_(grad, 1 - beta1)
+    v = fmaf(1.f - beta2, g * g, beta2 * v);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) / bias_c2_sqrt + eps;
+    p -= step_size * (m / denom);                             // param.addcdiv_(exp_avg, denom, value=-step_size)
+  };
+  if (vec) {
+    const int64_t n4 = (i1 - i0) / 4;
+    for (int64_t q = threadIdx.x; q < n4; q += 256) {
+      const int64_t i = i0 + 4 * q;
+      float4 p = *(float4*)(t.p + i), m = *(float4*)(t.m + i), v = *(float4*)(t.v + i);
+      const float4 g = *(const float4*)(t.g + i);
+      update(p.x, g.x, m.x, v.x); update(p.y, g.y, m.y, v.y); update(p.z, g.z, m.z, v.z); update(p.w, g.w, m.w, v.w);
+      *(float4*)(t.p + i) = p; *(float4*)(t.m + i) = m; *(float4*)(t.v + i) = v;
+    }
+    for (int64_t i = i0 + 4 * n4 + threadIdx.x; i < i1; i += 256) update(t.p[i], t.g[i], t.m[i], t.v[i]);
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) update(t.p[i], t.g[i], t.m[i], t.v[i]);
+  }
+}
+
 }  // namespace
 
 int tribe_internal_softmax(const float* S, int64_t R, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p, hipStream_t stream);
@@ -339,6 +377,20 @@ extern "C" int tribe_scale_cols_fwd(const float* x, const float* rs, int64_t M, 
 extern "C" int tribe_cast_bf16_fwd(const float* x, int64_t n, uint16_t* y, void* stream) {
   TRIBE_REQUIRE(x && y && n > 0 && n % 4 == 0, "tribe_cast_bf16_fwd: n must be a positive multiple of 4");
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t tribe_adam_chunk_elems(void) { return ADAM_CHUNK; }
+
+extern "C" int tribe_adam_step(const tribe_adam_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int64_t step, int32_t decoupled, void* stream) {
+  TRIBE_REQUIRE(table && chunk_tensor && chunk_start, "tribe_adam_step: null pointer");
+  TRIBE_REQUIRE(n_chunks > 0 && n_chunks < (1ll << 31) && step >= 1, "tribe_adam_step: need chunks and a 1-based step count");
+  TRIBE_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "tribe_adam_step: bad hyper-parameters");
+  const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_start, lr, beta1,
+                     beta2, eps, weight_decay, (float)c1, (float)sqrt(c2), decoupled);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

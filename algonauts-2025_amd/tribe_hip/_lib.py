@@ -25,6 +25,7 @@ i64, i32, f32, vp, sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 
 
 # tribe_feature_piece as a numpy record (tables of pieces are built vectorised on the host and uploaded as bytes)
+ADAM_TENSOR_DTYPE = _np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8")], align=True)   # tribe_adam_tensor
 FEATURE_PIECE_DTYPE = _np.dtype([("src", "<u8"), ("ld", "<i8"), ("src_first", "<i4"), ("src_count", "<i4"), ("dst_first", "<i4"),
                                  ("dst_count", "<i4")], align=True)
 
@@ -207,6 +208,8 @@ SIGNATURES = {
     "tribe_word_bag_fwd": (C.c_int, [vp, i64, i64, vp, vp, i64, vp, i64, vp]),
     "tribe_transpose_f32_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
     "tribe_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tribe_adam_chunk_elems": (i64, []),
+    "tribe_adam_step": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, i32, vp]),
     "tribe_quantize_fp8_fwd": (C.c_int, [vp, i32, i64, i64, i64, f32, vp, i64, vp]),
     "tribe_absmax_fwd": (C.c_int, [vp, i32, i64, i64, i64, vp, i32, vp]),
     "tribe_weighted_sum_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp]),

@@ -479,6 +479,18 @@ int tribe_quantize_fp8_fwd(const void* x, int32_t x_dtype, int64_t M, int64_t K,
 /* out[0] = max(out[0] if accumulate else 0, max |x|)  (device float; calibration of the per-tensor scales) */
 int tribe_absmax_fwd(const void* x, int32_t x_dtype, int64_t M, int64_t K, int64_t ld, float* out, int32_t accumulate, void* stream);
 
+/* ---- optimiser step of pl_module.training_step's loop (grids/defaults.py:126-133: torch.optim.Adam, lr 1e-4, wd 0) ----
+ * One launch per parameter group: p, m (exp_avg), v (exp_avg_sq) updated in place from g with torch.optim.Adam's
+ * arithmetic (decoupled = 1: AdamW).  `step` is the 1-based count used for the bias corrections.  The work list cuts
+ * every tensor into chunks of tribe_adam_chunk_elems() elements: chunk c = elements [chunk_start[c], +chunk) of
+ * table[chunk_tensor[c]].  All three arrays live in device memory. */
+typedef struct tribe_adam_tensor {
+  float* p; const float* g; float* m; float* v; int64_t n;
+} tribe_adam_tensor;
+int64_t tribe_adam_chunk_elems(void);
+int tribe_adam_step(const tribe_adam_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int64_t step, int32_t decoupled, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

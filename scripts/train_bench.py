@@ -1,5 +1,5 @@
 """Training-step throughput (forward + backward + Adam) of the full-size TRIBE encoder on one MI355X.
-GPU box: python scripts/train_bench.py [B]"""
+GPU box: python scripts/train_bench.py [B] [torch-adam]"""
 import sys
 import time
 from pathlib import Path
@@ -20,7 +20,10 @@ torch.manual_seed(0)
 fdims = {"text": (L, D), "audio": (L, D), "video": (L, D)}
 model = FmriEncoderConfig(n_subjects=S).build(fdims, V, T).to(dev).train()
 bm = BrainModule(model, TorchLossConfig(name="MSELoss").build(), None, {})
-opt = torch.optim.Adam(model.parameters(), lr=1e-4)   # defaults.py:126-133 (stock torch optimizer, out of the HIP scope)
+from modeling_utils.optim import HipAdam  # noqa: E402
+
+stock = len(sys.argv) > 2 and sys.argv[2] == "torch-adam"
+opt = torch.optim.Adam(model.parameters(), lr=1e-4) if stock else HipAdam(model.parameters(), lr=1e-4)   # defaults.py:126-133
 g = torch.Generator().manual_seed(1)
 data = {m: torch.stack([torch.randn(L, D, T, generator=g).bfloat16() for _ in range(B)]).to(dev) for m in fdims}
 data["subject_id"] = (torch.arange(B) % S).view(B, 1).to(dev)

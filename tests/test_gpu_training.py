@@ -178,3 +178,36 @@ def test_training_step_with_contrastive_branch():
     bad = {k: v for k, v in worst.items() if v > 8e-2}
     assert not bad, f"gradient mismatch: {bad}"
     print("contrastive: max grad rel err", max(worst.values()))
+
+
+def test_hip_adam_matches_torch_adam():
+    """One launch per group vs torch.optim.Adam on the CPU (oracle), under a OneCycleLR schedule that moves lr AND beta1
+    every step (grids/defaults.py:126-141); ragged sizes exercise the chunking and the unaligned tail."""
+    from modeling_utils.optim import HipAdam
+
+    torch.manual_seed(0)
+    shapes = [(3072, 257), (5,), (1, 1024, 48), (16385,), (7, 3)]
+    for wd, decoupled in [(0.0, False), (0.01, False), (0.01, True)]:
+        ref = [torch.randn(s).requires_grad_() for s in shapes]
+        mine = [p.detach().clone().cuda().requires_grad_() for p in ref]
+        opt_ref = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref, lr=1e-3, weight_decay=wd)
+        opt = HipAdam(mine, lr=1e-3, weight_decay=wd, decoupled_weight_decay=decoupled)
+        sch_ref = torch.optim.lr_scheduler.OneCycleLR(opt_ref, max_lr=1e-2, total_steps=6, pct_start=0.3)
+        sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-2, total_steps=6, pct_start=0.3)
+        for step in range(5):
+            for a, b in zip(ref, mine):
+                g = torch.randn(a.shape) * (10.0 ** (step - 2))
+                a.grad, b.grad = g.clone(), g.clone().cuda()
+            opt_ref.step(), opt.step()
+            sch_ref.step(), sch.step()
+            assert opt.param_groups[0]["lr"] == opt_ref.param_groups[0]["lr"] and opt.param_groups[0]["betas"] == opt_ref.param_groups[0]["betas"]
+            for a, b in zip(ref, mine):
+                torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=2e-6, atol=2e-7)
+        sd = opt.state_dict()["state"][0]
+        assert set(sd) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["step"]) == 5.0
+        torch.testing.assert_close(sd["exp_avg_sq"].cpu(), opt_ref.state_dict()["state"][0]["exp_avg_sq"], rtol=3e-5, atol=1e-12)
+        assert all(p._version >= 5 for p in mine)                 # raw-pointer updates are visible to version-keyed caches
+    cpu_param = torch.zeros(3, requires_grad=True)
+    cpu_param.grad = torch.ones(3)
+    with pytest.raises(Exception):
+        HipAdam([cpu_param], lr=1e-3).step()                      # no CPU fallback
