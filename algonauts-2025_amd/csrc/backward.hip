@@ -13,13 +13,13 @@ __device__ __forceinline__ float ldf<unsigned short>(const unsigned short* p) { 
 
 // out[z][c][r] = in[z][r][c] (bf16), r zero-padded to R_pad; 64x64 tiles through LDS
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t R, int64_t C, int64_t s_z, int64_t s_r,
-                                                        unsigned short* __restrict__ out, int64_t so_z, int64_t R_pad) {
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t R, int64_t C, int64_t s_z, int64_t Z0, int64_t s_z0,
+                                                        int64_t s_r, unsigned short* __restrict__ out, int64_t so_z, int64_t R_pad) {
   __shared__ unsigned short tile[64][66];
   const int64_t z = blockIdx.z;
   const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const T* src = in + z * s_z;
+  const T* src = in + (z / Z0) * s_z + (z % Z0) * s_z0;   // two batch levels: z = z1 * Z0 + z0
 #pragma unroll 4
   for (int i = ty; i < 64; i += 4) {
     const int64_t r = r0 + i, c = c0 + tx;
@@ -259,10 +259,11 @@ extern "C" int tribe_transpose_bf16(const void* in, int32_t in_dtype, int64_t Z,
   TRIBE_REQUIRE(Z > 0 && R > 0 && C > 0 && R_pad >= R && s_r >= C && Z < 65536, "tribe_transpose_bf16: bad shape");
   dim3 grid((unsigned)((R_pad + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)Z);
   if (in_dtype == TRIBE_F32)
-    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, R, C, s_z, s_r, out, so_z, R_pad);
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, R, C, s_z, (int64_t)1, (int64_t)0, s_r,
+                       out, so_z, R_pad);
   else if (in_dtype == TRIBE_BF16)
     hipLaunchKernelGGL(transpose_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, R, C, s_z,
-                       s_r, out, so_z, R_pad);
+                       (int64_t)1, (int64_t)0, s_r, out, so_z, R_pad);
   else
     TRIBE_REQUIRE(false, "tribe_transpose_bf16: dtype must be f32 or bf16");
   TRIBE_LAUNCH_CHECK();
@@ -391,6 +392,22 @@ extern "C" int tribe_adam_step(const tribe_adam_tensor* table, const int32_t* ch
   const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_start, lr, beta1,
                      beta2, eps, weight_decay, (float)c1, (float)sqrt(c2), decoupled);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_transpose_bf16_b2(const void* in, int32_t in_dtype, int64_t Z1, int64_t Z0, int64_t R, int64_t C, int64_t s_z1, int64_t s_z0,
+                                       int64_t s_r, uint16_t* out, int64_t so_z, int64_t R_pad, void* stream) {
+  TRIBE_REQUIRE(in && out, "tribe_transpose_bf16_b2: null pointer");
+  TRIBE_REQUIRE(Z1 > 0 && Z0 > 0 && R > 0 && C > 0 && R_pad >= R && s_r >= C && Z1 * Z0 < 65536, "tribe_transpose_bf16_b2: bad shape");
+  dim3 grid((unsigned)((R_pad + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)(Z1 * Z0));
+  if (in_dtype == TRIBE_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, R, C, s_z1, Z0, s_z0, s_r, out, so_z, R_pad);
+  else if (in_dtype == TRIBE_BF16)
+    hipLaunchKernelGGL(transpose_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, R, C, s_z1, Z0, s_z0,
+                       s_r, out, so_z, R_pad);
+  else
+    TRIBE_REQUIRE(false, "tribe_transpose_bf16_b2: dtype must be f32 or bf16");
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

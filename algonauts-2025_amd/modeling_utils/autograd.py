@@ -302,12 +302,11 @@ class Attention(torch.autograd.Function):
 
 
 def _head_transpose(x: torch.Tensor, nb: int, h: int, T: int, d: int, ld: int, off: int) -> torch.Tensor:
-    """[nb, T, (h, d)] strided view -> bf16 [nb*h, d, T_pad] (one launch per batch element: heads are the z axis)."""
+    """[nb, T, (h, d)] strided view -> bf16 [nb*h, d, T_pad]: one launch, batch levels (sequence, head)."""
     Tp = ops.round_up(T, 64)
     out = torch.empty(nb * h, d, Tp, dtype=torch.bfloat16, device=x.device)
-    for b in range(nb):
-        check(lib().tribe_transpose_bf16(x.data_ptr() + x.element_size() * (off + b * T * ld), _DT[x.dtype], h, T, d, d, ld,
-                                         out.data_ptr() + 2 * b * h * d * Tp, d * Tp, Tp, _s()), "tribe_transpose_bf16")
+    check(lib().tribe_transpose_bf16_b2(x.data_ptr() + x.element_size() * off, _DT[x.dtype], nb, h, T, d, T * ld, d, ld, out.data_ptr(), d * Tp, Tp,
+                                        _s()), "tribe_transpose_bf16_b2")
     return out
 
 

@@ -191,6 +191,7 @@ SIGNATURES = {
     "tribe_w2vbert_workspace_bytes": (sz, [C.POINTER(W2vBertDesc)]),
     "tribe_w2vbert_fwd": (C.c_int, [C.POINTER(W2vBertDesc), vp, vp, sz, vp]),
     "tribe_transpose_bf16": (C.c_int, [vp, i32, i64, i64, i64, i64, i64, vp, i64, i64, vp]),
+    "tribe_transpose_bf16_b2": (C.c_int, [vp, i32, i64, i64, i64, i64, i64, i64, i64, vp, i64, i64, vp]),
     "tribe_colsum_fwd": (C.c_int, [vp, i32, vp, i64, i64, i64, vp, i32, vp]),
     "tribe_scalenorm_bwd": (C.c_int, [vp, vp, i32, vp, f32, f32, i64, i64, vp, vp, vp, vp, vp]),
     "tribe_softmax_bwd": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, f32, vp, i64, vp]),

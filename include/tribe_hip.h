@@ -378,6 +378,10 @@ size_t tribe_pearson_loss_workspace_bytes(int64_t V);
  * (s_z, s_r, 1).  Used for the transposed operands of the weight-gradient GEMMs and of attention backward. */
 int tribe_transpose_bf16(const void* in, int32_t in_dtype, int64_t Z, int64_t R, int64_t C, int64_t s_z, int64_t s_r,
                          uint16_t* out, int64_t so_z, int64_t R_pad, void* stream);
+/* the same with two batch levels (z = z1 * Z0 + z0 reads in + z1 * s_z1 + z0 * s_z0; out batch z contiguous at so_z):
+ * all (batch, head) slices of a fused [B*T, heads*dim] activation in one launch */
+int tribe_transpose_bf16_b2(const void* in, int32_t in_dtype, int64_t Z1, int64_t Z0, int64_t R, int64_t C, int64_t s_z1, int64_t s_z0,
+                            int64_t s_r, uint16_t* out, int64_t so_z, int64_t R_pad, void* stream);
 /* out[n] (+)= sum_m a[m, n] * (b ? b[m, n] : 1)   (bias, residual_scale and positional-embedding gradients) */
 int tribe_colsum_fwd(const void* a, int32_t a_dtype, const float* b, int64_t M, int64_t N, int64_t ld, float* out,
                      int32_t accumulate, void* stream);
