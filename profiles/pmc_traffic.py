@@ -29,10 +29,19 @@ fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    m = re.search(r"gemm_nt_\d+x\d+x64<(\d), (\d)>", k)
-    name = ROLES[int(m.group(2))] if m else ("attention" if "attn_fwd" in k else k.split("(")[0][-40:])
+    m = re.search(r"gemm_nt_\d+x\d+x64<(\d), (\d+)>", k)
+    if m:
+        role = int(m.group(2))
+        name = ROLES[role] if role < len(ROLES) else "ext_epilogue"
+        if int(m.group(1)) == 1 and role == 0:
+            name = "generic_bf16_out"
+    else:
+        name = "attention" if "attn_fwd" in k else k.split("(")[0][-40:]
     rd = fetch.get(k, 0.0) * 1024 * 2  # KiB -> bytes, x2 gfx950 under-count of wide reads
     wr = write.get(k, 0.0) * 1024
     out[name] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "launches_profiled": int(nf.get(k, nw.get(k, 0)))}
     print(f"{name:14s} read {rd / 1e6:9.1f} MB  write {wr / 1e6:9.1f} MB  per launch   ({k[:70]})")
-json.dump({k: v["hbm_bytes"] for k, v in out.items()} | {"_detail": out}, open("profiles/roofline_traffic.json", "w"), indent=1)
+# the per-launch figures only mean something for the batch they were collected at: usage
+#   python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <B per GPU of that run>
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else None
+json.dump({k: v["hbm_bytes"] for k, v in out.items()} | {"_sequences_per_gpu": batch, "_detail": out}, open("profiles/roofline_traffic.json", "w"), indent=1)
