@@ -20,7 +20,13 @@ def timed(fn, n=5, warm=2):
     return (time.perf_counter() - t0) / n
 
 
-def bench_llama():
+def build_llama():
+    """Full-size Llama-3.2-3B architecture with random weights -> (HipLlamaModel, vocab size)."""
+    model, vocab, _ = _llama()
+    return model, vocab
+
+
+def _llama():
     from data_utils.features.text import LLAMA_3P2_3B, HipLlamaModel
 
     cfg = dict(LLAMA_3P2_3B)
@@ -41,6 +47,11 @@ def bench_llama():
         sd[p + "post_attention_layernorm.weight"] = torch.ones(H)
     model = HipLlamaModel(cfg, sd)
     del sd
+    return model, vocab, (H, I, L, hq, hkv, dh, g)
+
+
+def bench_llama():
+    model, vocab, (H, I, L, hq, hkv, dh, g) = _llama()
     for B, T in ((8, 1024), (32, 1024)):
         ids = torch.randint(0, vocab, (B, T), generator=g)
         start, length = torch.full((B,), T - 5), torch.full((B,), 5)
@@ -78,7 +89,8 @@ def _rand_sd(hf_cls, cfg_cls, kwargs):
     return cfg, sd
 
 
-def bench_vjepa2():
+def build_vjepa2():
+    """Full-size V-JEPA2 ViT-g encoder architecture with random weights."""
     from transformers import VJEPA2Config, VJEPA2Model
 
     from data_utils.features.video import HipVJEPA2Encoder
@@ -86,7 +98,11 @@ def bench_vjepa2():
     cfg, sd = _rand_sd(VJEPA2Model, VJEPA2Config, dict(patch_size=16, crop_size=256, frames_per_clip=64, tubelet_size=2, hidden_size=1408,
                                                         in_chans=3, num_attention_heads=22, num_hidden_layers=40, mlp_ratio=48 / 11,
                                                         pred_hidden_size=64, pred_num_attention_heads=2, pred_num_hidden_layers=1))
-    enc = HipVJEPA2Encoder(cfg, sd)
+    return HipVJEPA2Encoder(cfg, sd)
+
+
+def bench_vjepa2():
+    enc = build_vjepa2()
     H, L, mlp, tok = 1408, 40, int(1408 * 48 / 11), 8192
     per_tok = L * (2 * H * 3 * H + 2 * H * H + 4 * H * mlp + 4 * tok * H)
     for B in (1, 2):
@@ -106,7 +122,8 @@ def bench_vjepa2():
     print("  fp8 vs bf16 token means, relative L2 error at layers 1 / 20 / 40:", [round(float(err[i]), 4) for i in (1, 20, 40)], flush=True)
 
 
-def bench_w2vbert():
+def build_w2vbert():
+    """Full-size Wav2Vec-BERT 2.0 architecture with random weights."""
     from transformers import Wav2Vec2BertConfig, Wav2Vec2BertModel
 
     from data_utils.features.audio import HipWav2Vec2Bert
@@ -115,7 +132,11 @@ def bench_w2vbert():
                                                                     num_attention_heads=16, intermediate_size=4096,
                                                                     feature_projection_input_dim=160, add_adapter=False,
                                                                     position_embeddings_type="relative_key"))
-    model = HipWav2Vec2Bert(cfg, sd)
+    return HipWav2Vec2Bert(cfg, sd)
+
+
+def bench_w2vbert():
+    model = build_w2vbert()
     H, L, I = 1024, 24, 4096
     for B, T in ((1, 3000), (8, 3000)):
         per_tok = L * (2 * 2 * 2 * H * I + 2 * H * 3 * H + 2 * H * H + 2 * H * 2 * H + 2 * H * H + 4 * T * H)
