@@ -242,6 +242,78 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// Whole-wave epilogue for INTERIOR tiles (every operand 16-byte accessible, no bounds): the accumulators of a wave's
+// NI x 4 sub-tiles -> C.  The generic path below re-loads its operands per sub-tile; every one of those loads ends in an
+// s_waitcnt vmcnt(0) that also waits for the STORES of the previous sub-tile (vmcnt counts loads and stores in order), so
+// a 256 x 256 tile paid ~32 serial store-drain + load round trips (voxel head: ~50 us per tile, against a 63 us K loop).
+// Here nothing inside the sub-tile loop waits on memory:
+//   * operands that depend on the column only (column bias, residual scale) or the row only (row bias) are loaded once;
+//   * the residual tile is fetched with LDS-DMA into the (now idle) GEMM staging buffers, 16 sub-tiles per round,
+//     lane-linear so that each lane later reads back exactly its own 16 bytes -- no VGPRs held, one wait per round.
+// Supported: bias none / column / row, act none / GELU, residual (+ scale).  Everything else takes the generic path.
+template <int OUT_BF16, int NI>
+__device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t (&acc)[NI][4], int64_t mw, int64_t nw, int lane,
+                                              char* lds_wave) {
+  const int64_t row0 = mw + ((lane >> 4) << 2) + (lane & 3);      // + 16 i
+  const int64_t col0 = nw + (((lane & 15) >> 2) << 2);            // + 16 j
+  const bool bias_col = g.bias_mode == TRIBE_BIAS_COL, bias_row = g.bias_mode == TRIBE_BIAS_ROW;
+  const bool res_scaled = c.res && g.res_scale;
+  float4 bcol[4], rsc[4];
+  static_for<4>([&](auto jt) {
+    constexpr int j = decltype(jt)::value;
+    if (bias_col) bcol[j] = *(const float4*)(c.bias + col0 + j * 16);
+    if (res_scaled) rsc[j] = *(const float4*)(g.res_scale + col0 + j * 16);
+  });
+  constexpr int ROUNDS = NI / 4;
+  static_for<ROUNDS>([&](auto rt) {
+    constexpr int round = decltype(rt)::value;
+    float brow[4];
+    if (bias_row) {
+      static_for<4>([&](auto it) { brow[decltype(it)::value] = c.bias[row0 + (round * 4 + decltype(it)::value) * 16]; });
+    }
+    if (c.res) {
+      static_for<16>([&](auto st) {
+        constexpr int s = decltype(st)::value, i = round * 4 + s / 4, j = s % 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)(c.res + (row0 + i * 16) * g.ldres + col0 + j * 16), (lptr_t)(lds_wave + s * 1024), 16, 0, 0);
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA's LDS writes are invisible to the compiler's own counters
+    }
+    static_for<16>([&](auto st) {
+      constexpr int s = decltype(st)::value, i4 = s / 4, i = round * 4 + i4, j = s % 4;
+      float v[4];
+      quad_transpose(acc[i][j], g.alpha, lane, v);
+      if (bias_row) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += brow[i4];
+      }
+      if (bias_col) { v[0] += bcol[j].x; v[1] += bcol[j].y; v[2] += bcol[j].z; v[3] += bcol[j].w; }
+      if (g.act == TRIBE_ACT_GELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = OUT_BF16 ? gelu_fast(v[k]) : gelu_erf(v[k]);
+      }
+      if (c.res) {
+        const float4 r = *(const float4*)(lds_wave + s * 1024 + lane * 16);
+        if (res_scaled) { v[0] += r.x * rsc[j].x; v[1] += r.y * rsc[j].y; v[2] += r.z * rsc[j].z; v[3] += r.w * rsc[j].w; }
+        else { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+      }
+      const int64_t idx = c.c_off + (row0 + i * 16) * g.ldc + col0 + j * 16;
+      if (OUT_BF16) {
+        u16x4_t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
+        *(u16x4_t*)((unsigned short*)c.C + idx) = o;
+      } else {
+        *(float4*)((float*)c.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    });
+  });
+}
+
+// true when epilogue_fast covers this launch's operators (tile position is checked by the caller)
+__device__ __forceinline__ bool epilogue_fast_ok(const tribe_gemm_desc& g, const EpiCtx& c) {
+  return c.vec && !g.rowadd && !g.gadd && !g.aux && (g.act == TRIBE_ACT_NONE || g.act == TRIBE_ACT_GELU);
+}
+
 // One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).
 template <int OUT_BF16, int EXT>
 __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t acc, int64_t mt0,
