@@ -232,9 +232,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   // through LDS to get whole-row 256-byte stores was measured 2x SLOWER (K = 64 probe: 158 vs 75 us f32, 138 vs 43 us
   // bf16 per 16384 x 3072 output): the extra LDS round trip costs more than the wider store segments save.
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
-  if (epilogue_fast_ok(g, ctx) && m0 + BM <= g.M && n0 + BN <= g.N) {
-    // interior tile: nothing inside the sub-tile loop waits on memory (gemm_common.h); the staging buffers are idle by now
-    epilogue_fast<OUT_BF16, 8>(g, ctx, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * 16384);
+  if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
+    // nothing inside the sub-tile loop waits on memory (gemm_common.h); the staging buffers are idle by now
+    epilogue_fast<OUT_BF16, 8, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * 16384);
     return;
   }
   static_for<32>([&](auto t) {
@@ -337,6 +337,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
   }
 
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
+  if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
+    // (the K loop ends with a barrier: every wave's fragment reads are done, the buffers can stage the residual)
+    epilogue_fast<OUT_BF16, 4, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 64, n0 + wc * 64, lane, smem + wave * 16384);
+    return;
+  }
   static_for<16>([&](auto t) {
     constexpr int i = decltype(t)::value / 4, j = decltype(t)::value % 4;
     epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc[i][j], m0 + wr * 64 + i * 16, n0 + wc * 64 + j * 16, lane);

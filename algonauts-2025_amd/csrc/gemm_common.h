@@ -250,14 +250,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   * operands that depend on the column only (column bias, residual scale) or the row only (row bias) are loaded once;
 //   * the residual tile is fetched with LDS-DMA into the (now idle) GEMM staging buffers, 16 sub-tiles per round,
 //     lane-linear so that each lane later reads back exactly its own 16 bytes -- no VGPRs held, one wait per round.
-// Supported: bias none / column / row, act none / GELU, residual (+ scale).  Everything else takes the generic path.
-template <int OUT_BF16, int NI>
+// Supported: bias none / column / row; act none / GELU (+ SwiGLU / GLU / SiLU in the EXT kernels); residual (+ scale); rows past M
+// masked.  Row / gathered adds, the training-only aux operands and tiles that cross N take the generic path.
+template <int OUT_BF16, int NI, int EXT>
 __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t (&acc)[NI][4], int64_t mw, int64_t nw, int lane,
                                               char* lds_wave) {
   const int64_t row0 = mw + ((lane >> 4) << 2) + (lane & 3);      // + 16 i
   const int64_t col0 = nw + (((lane & 15) >> 2) << 2);            // + 16 j
   const bool bias_col = g.bias_mode == TRIBE_BIAS_COL, bias_row = g.bias_mode == TRIBE_BIAS_ROW;
   const bool res_scaled = c.res && g.res_scale;
+  const bool pair_act = EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU);
   float4 bcol[4], rsc[4];
   static_for<4>([&](auto jt) {
     constexpr int j = decltype(jt)::value;
@@ -269,34 +271,53 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
     constexpr int round = decltype(rt)::value;
     float brow[4];
     if (bias_row) {
-      static_for<4>([&](auto it) { brow[decltype(it)::value] = c.bias[row0 + (round * 4 + decltype(it)::value) * 16]; });
+      static_for<4>([&](auto it) {
+        const int64_t r = row0 + (round * 4 + decltype(it)::value) * 16;
+        brow[decltype(it)::value] = r < g.M ? c.bias[r] : 0.f;
+      });
     }
     if (c.res) {
       static_for<16>([&](auto st) {
         constexpr int s = decltype(st)::value, i = round * 4 + s / 4, j = s % 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)(c.res + (row0 + i * 16) * g.ldres + col0 + j * 16), (lptr_t)(lds_wave + s * 1024), 16, 0, 0);
+        if (row0 + i * 16 < g.M)   // rows past M (bottom tile row): the lane neither fetches nor stores
+          __builtin_amdgcn_global_load_lds((gptr_t)(c.res + (row0 + i * 16) * g.ldres + col0 + j * 16), (lptr_t)(lds_wave + s * 1024), 16, 0, 0);
       });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA's LDS writes are invisible to the compiler's own counters
     }
     static_for<16>([&](auto st) {
       constexpr int s = decltype(st)::value, i4 = s / 4, i = round * 4 + i4, j = s % 4;
+      const int64_t row = row0 + i * 16;
       float v[4];
-      quad_transpose(acc[i][j], g.alpha, lane, v);
+      quad_transpose(acc[i][j], g.alpha, lane, v);   // all four lanes of a quad take part, including those whose row is past M
+      if (row >= g.M) return;
       if (bias_row) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += brow[i4];
       }
       if (bias_col) { v[0] += bcol[j].x; v[1] += bcol[j].y; v[2] += bcol[j].z; v[3] += bcol[j].w; }
+      if (pair_act) {
+        // column pairs -> two outputs in a C that is N/2 wide: SwiGLU silu(gate) * up (modeling_llama.py:177), GLU a * sigmoid(b)
+        const bool glu = g.act == TRIBE_ACT_GLU;
+        const float o0 = glu ? v[0] * sigmoid_f(v[1]) : silu_f(v[0]) * v[1];
+        const float o1 = glu ? v[2] * sigmoid_f(v[3]) : silu_f(v[2]) * v[3];
+        const int64_t oidx = c.c_off + row * g.ldc + ((col0 + j * 16) >> 1);
+        if (OUT_BF16) *(unsigned int*)((unsigned short*)c.C + oidx) = (unsigned int)f32_to_bf16(o0) | ((unsigned int)f32_to_bf16(o1) << 16);
+        else *(float2*)((float*)c.C + oidx) = make_float2(o0, o1);
+        return;
+      }
       if (g.act == TRIBE_ACT_GELU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = OUT_BF16 ? gelu_fast(v[k]) : gelu_erf(v[k]);
+      } else if (EXT && g.act == TRIBE_ACT_SILU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
       }
       if (c.res) {
         const float4 r = *(const float4*)(lds_wave + s * 1024 + lane * 16);
         if (res_scaled) { v[0] += r.x * rsc[j].x; v[1] += r.y * rsc[j].y; v[2] += r.z * rsc[j].z; v[3] += r.w * rsc[j].w; }
         else { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
       }
-      const int64_t idx = c.c_off + (row0 + i * 16) * g.ldc + col0 + j * 16;
+      const int64_t idx = c.c_off + row * g.ldc + col0 + j * 16;
       if (OUT_BF16) {
         u16x4_t o;
 #pragma unroll
@@ -309,9 +330,13 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
   });
 }
 
-// true when epilogue_fast covers this launch's operators (tile position is checked by the caller)
+// true when epilogue_fast covers this launch's operators; the caller checks that the tile does not cross N (rows past M
+// are masked per lane, so the bottom tile row of an M that is not a multiple of the tile still takes the fast path)
+template <int EXT>
 __device__ __forceinline__ bool epilogue_fast_ok(const tribe_gemm_desc& g, const EpiCtx& c) {
-  return c.vec && !g.rowadd && !g.gadd && !g.aux && (g.act == TRIBE_ACT_NONE || g.act == TRIBE_ACT_GELU);
+  const bool act_ok = g.act == TRIBE_ACT_NONE || g.act == TRIBE_ACT_GELU ||
+                      (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU || g.act == TRIBE_ACT_SILU));
+  return c.vec && !g.rowadd && !g.gadd && !g.aux && act_ok;
 }
 
 // One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).

@@ -184,6 +184,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_nt_256x256x128(const tribe_ge
   // through LDS to get whole-row 256-byte stores was measured 2x SLOWER (K = 64 probe: 158 vs 75 us f32, 138 vs 43 us
   // bf16 per 16384 x 3072 output): the extra LDS round trip costs more than the wider store segments save.
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
+  if (epilogue_fast_ok<EXT>(g, ctx) && n0 + BN <= g.N) {
+    epilogue_fast<OUT_BF16, 8, EXT>(g, ctx, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * 16384);
+    return;
+  }
   static_for<32>([&](auto t) {
     constexpr int i = decltype(t)::value / 4, j = decltype(t)::value % 4;
     epilogue_tile16<OUT_BF16, EXT>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * 64 + j * 16, lane);

@@ -62,15 +62,18 @@ def test_gemm_big_tiles_race_screen(ops):
         assert torch.equal(ops.gemm_nt(a, b, tile_hint=2), first)
 
 
-@pytest.mark.parametrize("M,N,hint", [(96, 160, 0), (96, 158, 0), (384, 320, 2)])
+@pytest.mark.parametrize("M,N,hint", [(96, 160, 0), (96, 158, 0), (384, 320, 2), (70, 256, 1), (1001, 512, 2), (257, 256, 2), (1000, 1024, 0)])
 def test_gemm_epilogues(ops, M, N, hint):
+    """Every operator of the epilogue, on tiles that take the generic path (N not a multiple of the tile, row / gathered adds)
+    and on tiles that take the wait-free interior path (N a multiple of the tile; M = 70 / 257 / 1001 end inside a quad of
+    lanes, which must still all take part in the register transpose)."""
     g = torch.Generator().manual_seed(3)
     K, T = 128, 32
     a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / K**0.5)
     bias, rs = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
     res = torch.randn(M, N, generator=g)
     rowadd = torch.randn(T, N, generator=g)
-    gadd, gidx = torch.randn(5, N, generator=g), torch.tensor([4, 0, 2] * 4)
+    gadd, gidx = torch.randn(5, N, generator=g), torch.tensor([4, 0, 2] * 11)
     A, B = _dev(a).bfloat16(), _dev(b).bfloat16()
     base = a @ b.t()
     # bias + gelu, bf16 out  (one bf16 rounding: rel 2^-8 worst case)
@@ -80,8 +83,13 @@ def test_gemm_epilogues(ops, M, N, hint):
     x = _dev(res.clone())
     ops.gemm_nt(A, B, bias=_dev(bias), res=x, res_scale=_dev(rs), out=x, tile_hint=hint)
     torch.testing.assert_close(x.cpu(), base + bias + res * rs, rtol=1e-5, atol=1e-4)
-    # alpha, row bias, rowadd (period T) and gathered add (div T)
+    # alpha + row bias alone (the voxel head's operators), f32 and bf16 out
     rb = torch.randn(M, generator=g)
+    out = ops.gemm_nt(A, B, alpha=0.25, bias=_dev(rb), bias_row=True, tile_hint=hint)
+    torch.testing.assert_close(out.cpu(), 0.25 * base + rb[:, None], rtol=1e-5, atol=1e-4)
+    out = ops.gemm_nt(A, B, res=_dev(res), out_dtype=torch.bfloat16, tile_hint=hint)
+    torch.testing.assert_close(out.float().cpu(), base + res, rtol=2**-7, atol=1e-3)
+    # alpha, row bias, rowadd (period T) and gathered add (div T)
     out = ops.gemm_nt(A, B, alpha=0.25, bias=_dev(rb), bias_row=True, rowadd=_dev(rowadd), rowadd_period=T, gadd=_dev(gadd),
                       gadd_index=_dev(gidx), gadd_div=T, tile_hint=hint)
     m = torch.arange(M)
