@@ -267,7 +267,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   * the residual tile is fetched with LDS-DMA into the (now idle) GEMM staging buffers, 16 sub-tiles per round,
 //     lane-linear so that each lane later reads back exactly its own 16 bytes -- no VGPRs held, one wait per round.
 // Supported: bias none / column / row; act none / GELU (+ SwiGLU / GLU / SiLU in the EXT kernels); residual (+ scale); rows past M
-// masked.  Row / gathered adds, the training-only aux operands and tiles that cross N take the generic path.
+// masked; in the EXT kernels also the training operators (pre-activation store, GELU' from the saved pre-activation).
+// Row / gathered adds and tiles that cross N take the generic path.
 template <int OUT_BF16, int NI, int EXT>
 __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t (&acc)[NI][4], int64_t mw, int64_t nw, int lane,
                                               char* lds_wave) {
@@ -300,6 +301,16 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
       });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA's LDS writes are invisible to the compiler's own counters
     }
+    // training dgrad through GELU: the saved bf16 pre-activations of the round, fetched together (32 VGPRs, EXT kernels only)
+    u16x4_t pre[EXT ? 16 : 1];
+    const bool gelu_bwd = EXT && g.act == TRIBE_ACT_GELU_BWD;
+    if (gelu_bwd) {
+      static_for<16>([&](auto st) {
+        constexpr int s = decltype(st)::value, i = round * 4 + s / 4, j = s % 4;
+        const int64_t r = row0 + i * 16;
+        pre[EXT ? s : 0] = r < g.M ? *(const u16x4_t*)((const unsigned short*)g.aux + c.c_off + r * g.ld_aux + col0 + j * 16) : u16x4_t{0, 0, 0, 0};
+      });
+    }
     static_for<16>([&](auto st) {
       constexpr int s = decltype(st)::value, i4 = s / 4, i = round * 4 + i4, j = s % 4;
       const int64_t row = row0 + i * 16;
@@ -322,6 +333,12 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
         return;
       }
       if (g.act == TRIBE_ACT_GELU) {
+        if (EXT && g.aux) {   // training forward: keep the pre-activation for the backward pass (one more store, nothing to wait for)
+          u16x4_t p;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) p[k] = f32_to_bf16(v[k]);
+          *(u16x4_t*)((unsigned short*)g.aux + c.c_off + row * g.ld_aux + col0 + j * 16) = p;
+        }
         if (OUT_BF16) {
           const f32x2_t lo = gelu_poly2(f32x2_t{v[0], v[1]}), hi = gelu_poly2(f32x2_t{v[2], v[3]});
           v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
@@ -329,6 +346,9 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
         }
+      } else if (gelu_bwd) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= gelu_grad(bf16_to_f32(pre[EXT ? s : 0][k]));
       } else if (EXT && g.act == TRIBE_ACT_SILU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
@@ -356,8 +376,8 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
 template <int EXT>
 __device__ __forceinline__ bool epilogue_fast_ok(const tribe_gemm_desc& g, const EpiCtx& c) {
   const bool act_ok = g.act == TRIBE_ACT_NONE || g.act == TRIBE_ACT_GELU ||
-                      (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU || g.act == TRIBE_ACT_SILU));
-  return c.vec && !g.rowadd && !g.gadd && !g.aux && act_ok;
+                      (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU || g.act == TRIBE_ACT_SILU || g.act == TRIBE_ACT_GELU_BWD));
+  return c.vec && !g.rowadd && !g.gadd && (EXT || !g.aux) && act_ok;
 }
 
 // One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).
