@@ -211,3 +211,19 @@ def test_hip_adam_matches_torch_adam():
     cpu_param.grad = torch.ones(3)
     with pytest.raises(Exception):
         HipAdam([cpu_param], lr=1e-3).step()                      # no CPU fallback
+
+
+@pytest.mark.parametrize("Z,R,Cc,pad_c", [(3, 70, 130, 0), (2, 1024, 384, 0), (1, 33, 5, 0), (4, 64, 64, 64), (2, 257, 36, 12)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transpose_bf16_vector_and_scalar_paths(Z, R, Cc, pad_c, dtype):
+    """out[z, c, r] = bf16(in[z, r, c]) on a strided view (row stride Cc + pad_c), rows padded to 64: aligned views take the
+    4-element vector path, odd strides the element path; both must be exact."""
+    from modeling_utils.autograd import transpose_bf16
+
+    g = torch.Generator().manual_seed(R)
+    full = torch.randn(Z, R, Cc + pad_c, generator=g).to(dtype).cuda()
+    got = transpose_bf16(full, Z, R, Cc, R * (Cc + pad_c), Cc + pad_c)
+    Rp = (R + 63) // 64 * 64
+    assert got.shape == (Z, Cc, Rp)
+    want = full[:, :, :Cc].to(torch.bfloat16).transpose(1, 2)
+    assert torch.equal(got[:, :, :R], want) and not got[:, :, R:].any()
