@@ -129,6 +129,69 @@ __global__ __launch_bounds__(256) void scalenorm_bwd_kernel(const float* __restr
   if (dg && lane == 0) atomicAdd(dg, gain_scale * dot * inv);
 }
 
+// Same with the row of x and dy held in registers (dim = 256 * NV): one pass over HBM, vector accesses, and ONE atomic
+// per workgroup for the gain gradient instead of one per row.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void scalenorm_bwd_reg_kernel(const float* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ g,
+                                                                float gain_scale, float eps, int64_t rows, const float* __restrict__ dres,
+                                                                const float* __restrict__ rs, float* __restrict__ dx, float* __restrict__ dg) {
+  __shared__ float dg_part[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+  constexpr int64_t dim = 256 * NV;
+  float contrib = 0.f;
+  if (row < rows) {
+    const float4* xr = (const float4*)(x + row * dim);
+    float4 xv[NV], dv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) xv[k] = xr[lane + 64 * k];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (sizeof(T) == 2) {
+        const u16x4_t h = ((const u16x4_t*)((const unsigned short*)dy + row * dim))[lane + 64 * k];
+        dv[k] = make_float4(bf16_to_f32(h[0]), bf16_to_f32(h[1]), bf16_to_f32(h[2]), bf16_to_f32(h[3]));
+      } else {
+        dv[k] = ((const float4*)((const float*)dy + row * dim))[lane + 64 * k];
+      }
+    }
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      ss += xv[k].x * xv[k].x + xv[k].y * xv[k].y + xv[k].z * xv[k].z + xv[k].w * xv[k].w;
+      dot += xv[k].x * dv[k].x + xv[k].y * dv[k].y + xv[k].z * dv[k].z + xv[k].w * dv[k].w;
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float norm = sqrtf(ss);
+    const float s = g[0] * gain_scale;
+    const bool clamped = norm < eps;
+    const float inv = 1.0f / fmaxf(norm, eps);
+    const float proj = clamped ? 0.f : dot * inv * inv;
+    const float k0 = s * inv;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float4 v = make_float4(k0 * (dv[k].x - xv[k].x * proj), k0 * (dv[k].y - xv[k].y * proj), k0 * (dv[k].z - xv[k].z * proj),
+                             k0 * (dv[k].w - xv[k].w * proj));
+      if (dres) {
+        const float4 r = ((const float4*)(dres + row * dim))[lane + 64 * k];
+        if (rs) {
+          const float4 q = ((const float4*)rs)[lane + 64 * k];
+          v.x += r.x * q.x; v.y += r.y * q.y; v.z += r.z * q.z; v.w += r.w * q.w;
+        } else {
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+      }
+      ((float4*)(dx + row * dim))[lane + 64 * k] = v;
+    }
+    contrib = gain_scale * dot * inv;
+  }
+  if (dg) {
+    if (lane == 0) dg_part[wv] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dg, dg_part[0] + dg_part[1] + dg_part[2] + dg_part[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* __restrict__ P, const float* __restrict__ dP,
                                                           int64_t rows, int64_t T, int64_t T_pad, int64_t ld_p, int64_t ld_dp,
                                                           float scale, unsigned short* __restrict__ dS, int64_t ld_ds) {
@@ -341,14 +404,25 @@ extern "C" int tribe_scalenorm_bwd(const float* x, const void* dy, int32_t dy_dt
   TRIBE_REQUIRE(x && dy && g && dx, "tribe_scalenorm_bwd: null pointer");
   TRIBE_REQUIRE(rows > 0 && dim > 0, "tribe_scalenorm_bwd: bad shape");
   dim3 grid((unsigned)((rows + 3) / 4));
-  if (dy_dtype == TRIBE_F32)
-    hipLaunchKernelGGL(scalenorm_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (const float*)dy, g, gain_scale, eps, rows,
-                       dim, dres, rs, dx, dg);
-  else if (dy_dtype == TRIBE_BF16)
-    hipLaunchKernelGGL(scalenorm_bwd_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, x, (const unsigned short*)dy, g,
-                       gain_scale, eps, rows, dim, dres, rs, dx, dg);
+  TRIBE_REQUIRE(dy_dtype == TRIBE_F32 || dy_dtype == TRIBE_BF16, "tribe_scalenorm_bwd: dy dtype must be f32 or bf16");
+  hipStream_t s = (hipStream_t)stream;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)(dres ? dres : x) | (uintptr_t)(rs ? rs : x)) % 16) == 0 && ((uintptr_t)dy % 16) == 0;
+#define TRIBE_SNB(NV)                                                                                                             \
+  do {                                                                                                                            \
+    if (dy_dtype == TRIBE_F32)                                                                                                    \
+      hipLaunchKernelGGL((scalenorm_bwd_reg_kernel<float, NV>), grid, dim3(256), 0, s, x, (const float*)dy, g, gain_scale, eps, rows, dres, rs, dx, dg); \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((scalenorm_bwd_reg_kernel<unsigned short, NV>), grid, dim3(256), 0, s, x, (const unsigned short*)dy, g, gain_scale, eps, \
+                         rows, dres, rs, dx, dg);                                                                                 \
+  } while (0)
+  if (aligned && dim == 3072) TRIBE_SNB(12);
+  else if (aligned && dim == 768) TRIBE_SNB(3);
+  else if (dy_dtype == TRIBE_F32)
+    hipLaunchKernelGGL(scalenorm_bwd_kernel<float>, grid, dim3(256), 0, s, x, (const float*)dy, g, gain_scale, eps, rows, dim, dres, rs, dx, dg);
   else
-    TRIBE_REQUIRE(false, "tribe_scalenorm_bwd: dy dtype must be f32 or bf16");
+    hipLaunchKernelGGL(scalenorm_bwd_kernel<unsigned short>, grid, dim3(256), 0, s, x, (const unsigned short*)dy, g, gain_scale, eps, rows,
+                       dim, dres, rs, dx, dg);
+#undef TRIBE_SNB
   TRIBE_LAUNCH_CHECK();
   return 0;
 }
