@@ -487,6 +487,10 @@ extern "C" int tribe_pack_features(const void* feat, int32_t dtype, int64_t B, i
   TRIBE_REQUIRE(K_pad >= K && K_pad % 8 == 0, "tribe_pack_features: K_pad=%lld must be >= %lld and a multiple of 8",
                 (long long)K_pad, (long long)K);
   TRIBE_REQUIRE(B < 65536, "tribe_pack_features: batch too large for one launch");
+  if (!layer_mean && (dtype == TRIBE_BF16 || dtype == TRIBE_F32))
+    // plain "b (l d) t -> b t (l d)" + cast: the vectorised transpose of backward.hip (4 elements per access), 2x this file's
+    // element-wise kernel -- which stays for the layer mean and for f64 inputs
+    return tribe_transpose_bf16(feat, dtype, B, L * D, T, L * D * T, T, dst, T * K_pad, K_pad, stream);
   // in[b][k][t] (k = l*D + d for "cat"; reduce over l for "mean") -> out[b][t][k]
   const int64_t s_z = L * D * T, s_i = T;
   const int64_t Lr = layer_mean ? L : 1, s_l = layer_mean ? D * T : 0;
