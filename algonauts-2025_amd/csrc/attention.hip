@@ -43,7 +43,12 @@ struct AttnCfg {
   static constexpr int PIECES = KV * CHUNKS / 64;  // 1 KiB glds pieces per tile
   static constexpr int PPW = (PIECES + WAVES - 1) / WAVES;  // pieces per wave (last ones may be idle)
   static constexpr int SWZ_MASK = (CHUNKS % 16 == 0) ? 15 : 7;
-  static constexpr int SMEM = 4 * TILE_BYTES;   // {K, V} x 2 buffers
+  // K/V tile ring.  Large heads run one workgroup per CU anyway (registers), so they can afford three slots: tile t + 2 is
+  // staged while tile t + 1 is still landing and tile t is consumed, behind a counted vmcnt -- one 32-key tile of work
+  // (~1.5 us at DH = 384) is shorter than an L2-miss round trip.  Small heads keep two slots: a third would push their LDS
+  // past half a CU and halve their occupancy (measured: V-JEPA2 +20 % time).
+  static constexpr int NBUF = DH >= 192 ? 3 : 2;
+  static constexpr int SMEM = NBUF * 2 * TILE_BYTES;
   static_assert(DH % 64 == 0, "dim_head must be a multiple of 64");
 };
 
@@ -151,13 +156,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
   int kv_end = T;  // keys this workgroup can see
   if (CAUSAL) { const int last_q = qb * 128 + 127; kv_end = (last_q + 1 < T) ? last_q + 1 : T; }
   const int ntiles = (kv_end + C::KV - 1) / C::KV;
+  // LDS-DMA loads issued by this wave per staged tile (K and V pieces): the 3-slot pipeline leaves exactly one tile in flight
+  int my_glds = 0;
+#pragma unroll
+  for (int i = 0; i < C::PPW; ++i) my_glds += (wave + C::WAVES * i < C::PIECES) ? 2 : 0;
+  auto wait_keep_one_tile = [&]() {  // s_waitcnt needs an immediate: my_glds is 0, 2, 4 or 6 (wave-uniform)
+    if (my_glds >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (my_glds == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (my_glds == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(C::NBUF == 2 || C::PPW <= 3, "wait_keep_one_tile handles up to 6 loads per tile and wave");
   stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (C::NBUF == 3 && ntiles > 1) { stage(1, C::KV); wait_keep_one_tile(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntiles) stage(cur ^ 1, (t + 1) * C::KV);
+    const int cur = t % C::NBUF;
+    if (C::NBUF == 2 && t + 1 < ntiles) stage(cur ^ 1, (t + 1) * C::KV);
     const char* kt = smem + cur * 2 * C::TILE_BYTES;
     const char* vt = kt + C::TILE_BYTES;
     if (!CAUSAL || t * C::KV <= q0 + 15) {  // wave-uniform: some key of this tile is visible to some row of this wave
@@ -248,8 +264,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
       }
     }
     }  // visible tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (C::NBUF == 3) {
+      // stage tile t + 2 into the slot tile t - 1 occupied (every wave left it at the previous barrier), then wait for tile
+      // t + 1 only: the loads of tile t + 2 stay in flight across the barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads of tile t are complete
+      if (t + 2 < ntiles) { stage((t + 2) % C::NBUF, (t + 2) * C::KV); wait_keep_one_tile(); }
+      else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ---- normalise and write: O^T[d = 16 dt + 4 fq + r][q = l15] -> out[q][h*DH + d], 4 consecutive d (8 bytes) per store ----
