@@ -134,7 +134,8 @@ extern "C" int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, in
 namespace {
 struct EncPlan {
   int64_t M, inner;
-  size_t xn_bytes, big_bytes, attn_bytes;
+  size_t xn_bytes, big_bytes, attn_bytes, norm_bytes;
+  bool fuse_norm;   // ScaleNorm folded into the GEMMs either side of it (needs whole 256-column tiles)
 };
 inline EncPlan enc_plan(const tribe_encoder_desc* d) {
   EncPlan p;
@@ -143,7 +144,9 @@ inline EncPlan enc_plan(const tribe_encoder_desc* d) {
   p.xn_bytes = align256((size_t)p.M * d->dim * 2);
   const int64_t wide = (4 * p.inner > d->ff_inner) ? 4 * p.inner : d->ff_inner;  // qkv | attn_out  aliases  ff hidden
   p.big_bytes = align256((size_t)p.M * wide * 2);
-  p.attn_bytes = tribe_attention_workspace_bytes(d->B, d->T, d->heads, d->dim_head);
+  p.attn_bytes = align256(tribe_attention_workspace_bytes(d->B, d->T, d->heads, d->dim_head));
+  p.fuse_norm = d->dim % 256 == 0 && p.inner % 256 == 0 && d->ff_inner % 256 == 0;
+  p.norm_bytes = p.fuse_norm ? align256((size_t)p.M * (d->dim / 64 + 1) * 4) : 0;   // partial sums of squares + the row factors
   return p;
 }
 inline int enc_validate(const tribe_encoder_desc* d) {
@@ -162,7 +165,7 @@ inline int enc_validate(const tribe_encoder_desc* d) {
 extern "C" size_t tribe_encoder_workspace_bytes(const tribe_encoder_desc* d) {
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   const EncPlan p = enc_plan(d);
-  return p.xn_bytes + p.big_bytes + p.attn_bytes;
+  return p.xn_bytes + p.big_bytes + p.attn_bytes + p.norm_bytes;
 }
 
 extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y, int32_t y_dtype, void* workspace,
@@ -181,16 +184,30 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
   uint16_t* ao = big + (size_t)M * 3 * inner;  // [M, inner]
   uint16_t* hbuf = big;                        // [M, ff_inner]  (qkv/ao are dead by then)
   void* attn_ws = (char*)workspace + p.xn_bytes + p.big_bytes;
+  float* ssq = (float*)((char*)workspace + p.xn_bytes + p.big_bytes + p.attn_bytes);   // [M, dim / 64] partial sums of squares
+  float* rowf = ssq + (size_t)M * (dim / 64);                                          // [M] ScaleNorm factors
+  const int64_t n_part = dim / 64;
   const float scale = 1.0f / sqrtf((float)d->dim_head);
+  // With whole 256-column tiles the pre-norms are folded into the GEMMs: the GEMM that writes x also leaves bf16(x) in `xn` and
+  // the per-row partial sums of squares; a [M]-sized kernel turns them into the ScaleNorm factors; the next GEMM reads the raw
+  // bf16(x) and scales its accumulator rows (W . (x s) = s (W . x)).  Only the first norm (x comes from the projector) and the
+  // final one (its consumer, the voxel head, has x on the column side) stay stand-alone launches: 2 instead of 2 * depth + 1.
+  const bool fuse = p.fuse_norm;
+  bool have_factors = false;   // rowf / xn describe the current x
 
   for (int l = 0; l < d->depth; ++l) {
     const tribe_encoder_layer& L = d->layers_host[l];
     TRIBE_REQUIRE(L.attn_norm_g && L.w_qkv && L.w_out && L.ff_norm_g && L.w_ff1 && L.b_ff1 && L.w_ff2 && L.b_ff2,
                   "tribe_encoder_fwd: layer %d has a null parameter", l);
     // ---- attention block: x = to_out(attn(rotary(qkv(norm(x))))) + x * residual_scale ----
-    rc = tribe_scalenorm_fwd(x, M, dim, L.attn_norm_g, d->norm_gain_scale, d->norm_eps, xn, TRIBE_BF16, stream);
-    if (rc) return rc;
     tribe_gemm_desc g = gemm_zero();
+    if (have_factors) {
+      rc = tribe_rownorm_scale_fwd(ssq, M, n_part, L.attn_norm_g, d->norm_gain_scale, d->norm_eps, rowf, stream);
+      g.row_scale = rowf;
+    } else {
+      rc = tribe_scalenorm_fwd(x, M, dim, L.attn_norm_g, d->norm_gain_scale, d->norm_eps, xn, TRIBE_BF16, stream);
+    }
+    if (rc) return rc;
     g.M = M; g.N = 3 * inner; g.K = dim;
     g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
     g.C = qkv; g.ldc = 3 * inner; g.c_dtype = TRIBE_BF16;
@@ -209,12 +226,18 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32;
     g.res = x; g.ldres = dim; g.res_scale = L.attn_res_scale;
     g.role = TRIBE_ROLE_OUT_PROJ;
+    if (fuse) { g.c_bf16 = xn; g.ld_c_bf16 = dim; g.row_sumsq = ssq; g.ld_row_sumsq = n_part; }
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     // ---- feed-forward block: x = W2 gelu(W1 norm(x) + b1) + b2 + x * residual_scale ----
-    rc = tribe_scalenorm_fwd(x, M, dim, L.ff_norm_g, d->norm_gain_scale, d->norm_eps, xn, TRIBE_BF16, stream);
-    if (rc) return rc;
     g = gemm_zero();
+    if (fuse) {
+      rc = tribe_rownorm_scale_fwd(ssq, M, n_part, L.ff_norm_g, d->norm_gain_scale, d->norm_eps, rowf, stream);
+      g.row_scale = rowf;
+    } else {
+      rc = tribe_scalenorm_fwd(x, M, dim, L.ff_norm_g, d->norm_gain_scale, d->norm_eps, xn, TRIBE_BF16, stream);
+    }
+    if (rc) return rc;
     g.M = M; g.N = d->ff_inner; g.K = dim;
     g.A = xn; g.lda = dim; g.B = L.w_ff1; g.ldb = dim;
     g.C = hbuf; g.ldc = d->ff_inner; g.c_dtype = TRIBE_BF16;
@@ -229,6 +252,8 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.bias = L.b_ff2; g.bias_mode = TRIBE_BIAS_COL;
     g.res = x; g.ldres = dim; g.res_scale = L.ff_res_scale;
     g.role = TRIBE_ROLE_FF2;
+    have_factors = fuse && l + 1 < d->depth;   // the next layer's QKV takes the raw bf16(x) + factors
+    if (have_factors) { g.c_bf16 = xn; g.ld_c_bf16 = dim; g.row_sumsq = ssq; g.ld_row_sumsq = n_part; }
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
   }

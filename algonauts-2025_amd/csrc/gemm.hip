@@ -415,6 +415,27 @@ extern "C" int tribe_prof_end(int32_t n_roles, double* total_ms_host, int64_t* c
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void rownorm_scale_kernel(const float* __restrict__ partial, int64_t rows, int64_t n_partial,
+                                                            const float* __restrict__ g, float gain_scale, float eps, float* __restrict__ scale) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= rows) return;
+  const float* p = partial + m * n_partial;
+  float ss = 0.f;
+  for (int64_t i = 0; i < n_partial; ++i) ss += p[i];
+  scale[m] = g[0] * gain_scale / fmaxf(sqrtf(ss), eps);
+}
+}  // namespace
+
+extern "C" int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partial, const float* g, float gain_scale, float eps,
+                                       float* scale, void* stream) {
+  TRIBE_REQUIRE(partial && g && scale && rows > 0 && n_partial > 0, "tribe_rownorm_scale_fwd: bad argument");
+  hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, rows, n_partial, g,
+                     gain_scale, eps, scale);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(d != nullptr, "tribe_gemm_bf16: null descriptor");
   TRIBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "tribe_gemm_bf16: M, N, K must be positive (got %lld %lld %lld)",
@@ -438,6 +459,17 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(d->act != TRIBE_ACT_GELU_BWD || d->aux, "tribe_gemm_bf16: GELU_BWD needs the saved pre-activation in aux");
   TRIBE_REQUIRE(!d->aux || (d->ld_aux >= d->N && d->batch1 * d->batch0 == 1), "tribe_gemm_bf16: aux is supported for un-batched GEMMs");
   const int64_t nz = d->batch1 * d->batch0;
+  if (d->c_bf16 || d->row_sumsq || d->row_scale) {
+    // fused ScaleNorm operands exist only in the wait-free epilogue: insist on everything that path needs
+    TRIBE_REQUIRE(nz == 1 && d->N % 256 == 0 && !d->rowadd && !d->gadd && !d->aux && (d->act == TRIBE_ACT_NONE || d->act == TRIBE_ACT_GELU),
+                  "tribe_gemm_bf16: c_bf16 / row_sumsq / row_scale need an un-batched launch with N %% 256 == 0 and plain operators");
+    TRIBE_REQUIRE(d->ldc % 4 == 0 && ((uintptr_t)d->C % 16) == 0 && (!d->bias || ((uintptr_t)d->bias % 16) == 0) &&
+                      (!d->res || (d->ldres % 4 == 0 && ((uintptr_t)d->res % 16) == 0)) && (!d->res_scale || ((uintptr_t)d->res_scale % 16) == 0),
+                  "tribe_gemm_bf16: c_bf16 / row_sumsq / row_scale need 16-byte aligned operands");
+    TRIBE_REQUIRE((!d->c_bf16 && !d->row_sumsq) || d->c_dtype == TRIBE_F32, "tribe_gemm_bf16: c_bf16 / row_sumsq accompany an f32 C");
+    TRIBE_REQUIRE(!d->c_bf16 || (d->ld_c_bf16 >= d->N && d->ld_c_bf16 % 4 == 0 && ((uintptr_t)d->c_bf16 % 8) == 0), "tribe_gemm_bf16: bad c_bf16");
+    TRIBE_REQUIRE(!d->row_sumsq || d->ld_row_sumsq >= d->N / 64, "tribe_gemm_bf16: ld_row_sumsq must cover N / 64 slots");
+  }
   // tile selection: 256^2 tiles when both extents fill them and the grid still covers the chip, else 128^2
   int use_big = (d->M >= 256 && d->N >= 256 && ((d->M + 255) / 256) * ((d->N + 255) / 256) * nz >= 96);
   if (d->tile_hint == 1) use_big = 0;

@@ -286,11 +286,17 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
   constexpr int ROUNDS = NI / 4;
   static_for<ROUNDS>([&](auto rt) {
     constexpr int round = decltype(rt)::value;
-    float brow[4];
+    float brow[4], srow[4], ssq[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias_row) {
       static_for<4>([&](auto it) {
         const int64_t r = row0 + (round * 4 + decltype(it)::value) * 16;
         brow[decltype(it)::value] = r < g.M ? c.bias[r] : 0.f;
+      });
+    }
+    if (g.row_scale) {   // ScaleNorm of the A rows, applied to the product (see tribe_gemm_desc)
+      static_for<4>([&](auto it) {
+        const int64_t r = row0 + (round * 4 + decltype(it)::value) * 16;
+        srow[decltype(it)::value] = r < g.M ? g.row_scale[r] : 0.f;
       });
     }
     if (c.res) {
@@ -317,6 +323,10 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
       float v[4];
       quad_transpose(acc[i][j], g.alpha, lane, v);   // all four lanes of a quad take part, including those whose row is past M
       if (row >= g.M) return;
+      if (g.row_scale) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= srow[i4];
+      }
       if (bias_row) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += brow[i4];
@@ -366,8 +376,26 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
         *(u16x4_t*)((unsigned short*)c.C + idx) = o;
       } else {
         *(float4*)((float*)c.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.c_bf16) {   // the next GEMM's A operand, un-normalised (its ScaleNorm factor rides in that GEMM's row_scale)
+          u16x4_t o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
+          *(u16x4_t*)(g.c_bf16 + row * g.ld_c_bf16 + col0 + j * 16) = o;
+        }
+        if (g.row_sumsq) ssq[i4] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
       }
     });
+    if (!OUT_BF16 && g.row_sumsq) {
+      // the 16 values a lane holds of row i (4 sub-tiles x 4 columns) + the three other lanes of that row -> one slot per wave
+      static_for<4>([&](auto it) {
+        constexpr int i4 = decltype(it)::value;
+        float t = ssq[i4];
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        const int64_t r = row0 + (round * 4 + i4) * 16;
+        if ((lane & 12) == 0 && r < g.M) g.row_sumsq[r * g.ld_row_sumsq + (nw >> 6)] = t;
+      });
+    }
   });
 }
 
@@ -377,7 +405,7 @@ template <int EXT>
 __device__ __forceinline__ bool epilogue_fast_ok(const tribe_gemm_desc& g, const EpiCtx& c) {
   const bool act_ok = g.act == TRIBE_ACT_NONE || g.act == TRIBE_ACT_GELU ||
                       (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU || g.act == TRIBE_ACT_SILU || g.act == TRIBE_ACT_GELU_BWD));
-  return c.vec && !g.rowadd && !g.gadd && (EXT || !g.aux) && act_ok;
+  return c.vec && !g.rowadd && !g.gadd && (EXT || !g.aux) && act_ok;   // (the launcher refuses the fused-norm operands unless this holds)
 }
 
 // One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).

@@ -49,6 +49,7 @@ class GemmDesc(C.Structure):
         ("gadd", vp), ("gadd_index", vp), ("gadd_div", i64), ("ld_gadd", i64),
         ("aux", vp), ("ld_aux", i64), ("gather_b", i32),
         ("role", i32), ("tile_hint", i32),
+        ("c_bf16", vp), ("ld_c_bf16", i64), ("row_sumsq", vp), ("ld_row_sumsq", i64), ("row_scale", vp),
     ]
 
 
@@ -209,6 +210,7 @@ SIGNATURES = {
     "tribe_word_bag_fwd": (C.c_int, [vp, i64, i64, vp, vp, i64, vp, i64, vp]),
     "tribe_transpose_f32_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
     "tribe_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tribe_rownorm_scale_fwd": (C.c_int, [vp, i64, i64, vp, f32, f32, vp, vp]),
     "tribe_adam_chunk_elems": (i64, []),
     "tribe_adam_step": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, i32, vp]),
     "tribe_quantize_fp8_fwd": (C.c_int, [vp, i32, i64, i64, i64, f32, vp, i64, vp]),

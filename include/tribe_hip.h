@@ -84,9 +84,21 @@ typedef struct tribe_gemm_desc {
   int32_t gather_b;        /* gather1 also replaces b1 for the B operand */
   int32_t role;            /* enum tribe_gemm_role */
   int32_t tile_hint;       /* 0 = automatic, 1 = force 128x128 tiles, 2 = force 256x256 tiles (tests / tuning) */
+  /* ScaleNorm folded into the GEMMs either side of it (x_transformers pre-norm: y = W . (x * s_m), s_m = g sqrt(d) / |x_m|):
+   * the PRODUCER of x (f32 C) also emits a bf16 copy and per-row partial sums of squares, one slot per 64 output columns
+   * (row_sumsq[m * ld_row_sumsq + n / 64]); tribe_rownorm_scale_fwd turns them into s_m; the CONSUMER multiplies its
+   * accumulator rows by row_scale[m] before bias / activation (the scaling commutes with the product).  Un-batched
+   * launches whose N is a multiple of the tile and whose operands are 16-byte aligned only; NULL = unused. */
+  uint16_t* c_bf16; int64_t ld_c_bf16;
+  float* row_sumsq; int64_t ld_row_sumsq;
+  const float* row_scale;
 } tribe_gemm_desc;
 
 int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);
+/* scale[m] = g[0] * gain_scale / max(sqrt(sum_p partial[m, p]), eps): the ScaleNorm factor from the partial sums of squares a
+ * GEMM epilogue left in row_sumsq (partial f32 [rows, n_partial], row-major). */
+int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partial, const float* g, float gain_scale, float eps,
+                            float* scale, void* stream);
 
 /* Measurement hook (bench.py): while enabled, every GEMM launch is bracketed by HIP events on ITS
  * stream.  tribe_prof_end synchronises them and returns, per role, the summed kernel time (ms), the
