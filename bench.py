@@ -48,18 +48,19 @@ def build_model(device: torch.device):
 
     torch.manual_seed(0)
     fdims = {"text": (L, D), "audio": (L, D), "video": (L, D)}
-    model = FmriEncoderConfig(n_subjects=S).build(fdims, n_outputs=V, n_output_timesteps=T).eval()
+    with torch.device(device):   # random-init the 0.94 G parameters on the GPU: eight ranks sharing the host cores would crawl
+        model = FmriEncoderConfig(n_subjects=S).build(fdims, n_outputs=V, n_output_timesteps=T).eval()
     return model.to(device), fdims
 
 
 def make_batch(B: int, fdims, device: torch.device, seed: int):
     from data_utils.dataloader import SegmentData
 
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
     data = {}
     for m, (l, d) in fdims.items():
-        # generated per sequence to bound host memory, then resident on the GPU in bf16
-        data[m] = torch.stack([torch.randn(l, d, T, generator=g).to(torch.bfloat16) for _ in range(B)]).to(device)
+        # synthetic N(0, 1) features, drawn on the GPU per sequence (bounded f32 scratch) and kept resident in bf16
+        data[m] = torch.stack([torch.randn(l, d, T, generator=g, device=device).to(torch.bfloat16) for _ in range(B)])
     data["subject_id"] = (torch.arange(B) % S).view(B, 1).to(device)
     return SegmentData(data=data, segments=[None] * B)
 
