@@ -268,7 +268,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 //     lane-linear so that each lane later reads back exactly its own 16 bytes -- no VGPRs held, one wait per round.
 // Supported: bias none / column / row; act none / GELU (+ SwiGLU / GLU / SiLU in the EXT kernels); residual (+ scale); rows past M
 // masked; in the EXT kernels also the training operators (pre-activation store, GELU' from the saved pre-activation).
-// Row / gathered adds and tiles that cross N take the generic path.
+// The periodic row add (pos_embed) takes the residual's place when there is no residual; gathered adds, a row add together
+// with a residual, and tiles that cross N take the generic path.
 template <int OUT_BF16, int NI, int EXT>
 __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t (&acc)[NI][4], int64_t mw, int64_t nw, int lane,
                                               char* lds_wave) {
@@ -299,11 +300,20 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
         srow[decltype(it)::value] = r < g.M ? g.row_scale[r] : 0.f;
       });
     }
-    if (c.res) {
-      static_for<16>([&](auto st) {
-        constexpr int s = decltype(st)::value, i = round * 4 + s / 4, j = s % 4;
-        if (row0 + i * 16 < g.M)   // rows past M (bottom tile row): the lane neither fetches nor stores
-          __builtin_amdgcn_global_load_lds((gptr_t)(c.res + (row0 + i * 16) * g.ldres + col0 + j * 16), (lptr_t)(lds_wave + s * 1024), 16, 0, 0);
+    // the tile-shaped addend: the residual, or (when there is none) the periodic row add -- pos_embed[t] of the projector
+    const bool tile_add = c.res || g.rowadd;
+    if (tile_add) {
+      static_for<4>([&](auto it) {
+        constexpr int i4 = decltype(it)::value, i = round * 4 + i4;
+        const int64_t r = row0 + i * 16;
+        if (r < g.M) {   // rows past M (bottom tile row): the lane neither fetches nor stores
+          const float* src = c.res ? c.res + r * g.ldres + col0
+                                   : g.rowadd + (int64_t)((unsigned)r % (unsigned)g.rowadd_period) * g.ld_rowadd + col0;
+          static_for<4>([&](auto jt) {
+            constexpr int j = decltype(jt)::value;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 16), (lptr_t)(lds_wave + (i4 * 4 + j) * 1024), 16, 0, 0);
+          });
+        }
       });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA's LDS writes are invisible to the compiler's own counters
     }
@@ -363,7 +373,7 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
       }
-      if (c.res) {
+      if (tile_add) {
         const float4 r = *(const float4*)(lds_wave + s * 1024 + lane * 16);
         if (res_scaled) { v[0] += r.x * rsc[j].x; v[1] += r.y * rsc[j].y; v[2] += r.z * rsc[j].z; v[3] += r.w * rsc[j].w; }
         else { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
@@ -405,7 +415,8 @@ template <int EXT>
 __device__ __forceinline__ bool epilogue_fast_ok(const tribe_gemm_desc& g, const EpiCtx& c) {
   const bool act_ok = g.act == TRIBE_ACT_NONE || g.act == TRIBE_ACT_GELU ||
                       (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU || g.act == TRIBE_ACT_SILU || g.act == TRIBE_ACT_GELU_BWD));
-  return c.vec && !g.rowadd && !g.gadd && (EXT || !g.aux) && act_ok;   // (the launcher refuses the fused-norm operands unless this holds)
+  const bool rowadd_ok = !g.rowadd || (!c.res && g.M < (1ll << 31) && g.rowadd_period < (1ll << 31));   // rides in the residual's LDS slot
+  return c.vec && rowadd_ok && !g.gadd && (EXT || !g.aux) && act_ok;   // (the launcher refuses the fused-norm operands unless this holds)
 }
 
 // One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).

@@ -89,6 +89,9 @@ def test_gemm_epilogues(ops, M, N, hint):
     torch.testing.assert_close(out.cpu(), 0.25 * base + rb[:, None], rtol=1e-5, atol=1e-4)
     out = ops.gemm_nt(A, B, res=_dev(res), out_dtype=torch.bfloat16, tile_hint=hint)
     torch.testing.assert_close(out.float().cpu(), base + res, rtol=2**-7, atol=1e-3)
+    # column bias + periodic row add alone (the projector's operators: pos_embed[t] rides in the residual's LDS slot on interior tiles)
+    out = ops.gemm_nt(A, B, bias=_dev(bias), rowadd=_dev(rowadd), rowadd_period=T, tile_hint=hint)
+    torch.testing.assert_close(out.cpu(), base + bias + rowadd[torch.arange(M) % T], rtol=1e-5, atol=1e-4)
     # alpha, row bias, rowadd (period T) and gathered add (div T)
     out = ops.gemm_nt(A, B, alpha=0.25, bias=_dev(rb), bias_row=True, rowadd=_dev(rowadd), rowadd_period=T, gadd=_dev(gadd),
                       gadd_index=_dev(gidx), gadd_div=T, tile_hint=hint)
