@@ -90,3 +90,67 @@ def test_shard_indices_cover_and_partition():
     inv = D.unshard_order(8, 4)
     order = [i for r in range(4) for i in D.shard_indices(8, r, 4)]
     assert [order[p] for p in inv] == list(range(8))
+
+
+def _replica_worker(rank: int, world: int, port: int, q):
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "algonauts-2025_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from algonauts2025.grids.replicas import expand_grid, my_replicas, run_replicas
+
+        configs = expand_grid({"seed": list(range(5)), "data.layers": [[0, 0.5, 1], [0.5, 1.0]]}, combinatorial=True)
+        ran = []
+
+        def fn(cfg):
+            ran.append(cfg["seed"])
+            return {"seed": cfg["seed"], "n_layers": len(cfg["data.layers"]), "rank": dist.get_rank()}
+
+        out = run_replicas(fn, configs)
+        q.put((rank, len(ran), my_replicas(len(configs), rank, world), out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replica_scheduling_two_ranks_and_grid_expansion():
+    """BASELINE config 5 host logic: grid expansion as the reference's run_grid (utils.py:104-117), round-robin replicas over
+    ranks, results gathered in configuration order on rank 0."""
+    import itertools
+    import random
+
+    from algonauts2025.grids.replicas import apply_overrides, expand_grid, replica_name
+
+    grid = {"a": [1, 2, 3], "b.c": ["x", "y"]}
+    comb = expand_grid(grid, combinatorial=True)
+    assert comb == [dict(zip(grid.keys(), v)) for v in itertools.product(*grid.values())] and len(comb) == 6
+    assert expand_grid(grid) == [{"a": 1}, {"a": 2}, {"a": 3}, {"b.c": "x"}, {"b.c": "y"}]
+    assert expand_grid(grid, combinatorial=True, n_randomly_sampled=4, rng=random.Random(3)) == random.Random(3).sample(comb, 4)
+    with pytest.raises(AssertionError):
+        expand_grid(grid, combinatorial=True, n_randomly_sampled=7)
+    with pytest.raises(AssertionError):
+        expand_grid({"a": 1})
+    base = {"data": {"layers": [0.5], "other": 1}, "seed": 0}
+    cfg = apply_overrides(base, {"data.layers": [0, 1], "loss.name": "PearsonLoss", "seed": 4})
+    assert cfg == {"data": {"layers": [0, 1], "other": 1}, "seed": 4, "loss": {"name": "PearsonLoss"}} and base["seed"] == 0
+    assert replica_name({"a": 1, "b": 2}) == replica_name({"b": 2, "a": 1}) != replica_name({"a": 1, "b": 3})
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r[0]: r for r in (q.get(timeout=180) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] == 5 and results[1][1] == 5                      # 10 replicas, 5 each
+    assert results[0][2] == [0, 2, 4, 6, 8] and results[1][2] == [1, 3, 5, 7, 9]
+    assert results[1][3] is None
+    out = results[0][3]
+    assert [o["seed"] for o in out] == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4] and [o["rank"] for o in out] == [0, 1] * 5
+    assert [o["n_layers"] for o in out] == [3, 2] * 5
