@@ -106,6 +106,55 @@ def test_gemm_epilogues(ops, M, N, hint):
         ops.gemm_nt(_dev(torch.zeros(8, 48)).bfloat16(), _dev(torch.zeros(8, 48)).bfloat16())  # K % 64
 
 
+def test_gemm_epilogue_fuzz(ops):
+    """Random shapes x random operator sets x both tile sizes against an f64 reference: the wait-free interior epilogue, the
+    generic edge epilogue and the masked bottom rows must agree on every combination (48 seeded cases)."""
+    rng = np.random.default_rng(2025)
+    for case in range(48):
+        hint = int(rng.integers(1, 3))
+        tile = 128 if hint == 1 else 256
+        M = int(rng.choice([int(rng.integers(1, 3 * tile)), tile, 2 * tile + 3]))
+        N = int(rng.choice([tile, 2 * tile, int(rng.integers(1, 2 * tile)) // 4 * 4 + 4]))
+        K = 64 * int(rng.integers(1, 5))
+        g = torch.Generator().manual_seed(case)
+        a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / K**0.5)
+        use_bias = int(rng.integers(0, 3))          # 0 none, 1 column, 2 row
+        use_res, use_rs, use_gelu, use_rowadd = (bool(rng.integers(0, 2)) for _ in range(4))
+        out_bf16 = bool(rng.integers(0, 2))
+        alpha = float(rng.choice([1.0, 0.5]))
+        kw = {"alpha": alpha, "tile_hint": hint, "out_dtype": torch.bfloat16 if out_bf16 else torch.float32}
+        want = alpha * (a.double() @ b.double().t())
+        if use_bias == 1:
+            bias = torch.randn(N, generator=g)
+            kw["bias"] = _dev(bias)
+            want = want + bias.double()
+        elif use_bias == 2:
+            bias = torch.randn(M, generator=g)
+            kw["bias"], kw["bias_row"] = _dev(bias), True
+            want = want + bias.double()[:, None]
+        if use_gelu:
+            kw["act"] = "gelu"
+            want = torch.nn.functional.gelu(want)
+        if use_res:
+            res = torch.randn(M, N, generator=g)
+            kw["res"] = _dev(res)
+            if use_rs:
+                rs = torch.rand(N, generator=g) + 0.5
+                kw["res_scale"] = _dev(rs)
+                want = want + res.double() * rs.double()
+            else:
+                want = want + res.double()
+        if use_rowadd:
+            T = int(rng.integers(1, M + 1))
+            ra = torch.randn(T, N, generator=g)
+            kw["rowadd"], kw["rowadd_period"] = _dev(ra), T
+            want = want + ra.double()[torch.arange(M) % T]
+        got = ops.gemm_nt(_dev(a).bfloat16(), _dev(b).bfloat16(), **kw).double().cpu()
+        tol = 2**-7 if out_bf16 else 1e-4
+        err = (got - want).abs().max() / max(1.0, float(want.abs().max()))
+        assert err < tol, (case, M, N, K, hint, use_bias, use_res, use_rs, use_gelu, use_rowadd, out_bf16, float(err))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64])
 @pytest.mark.parametrize("layer_mean", [False, True])
 def test_pack_features(ops, dtype, layer_mean):
