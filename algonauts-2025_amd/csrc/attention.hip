@@ -65,6 +65,7 @@ struct AttnArgs {
   int T, heads_q, group;  // group = heads_q / heads_kv
   float scale_log2e;
   int qblocks;
+  int n_bh;   // batch * heads_q: the (sequence, head) pairs
   // relative_key position bias (Wav2Vec2BertSelfAttention, modeling_wav2vec2_bert.py:308-320): score += q . E[clamp(j - i)]
   const float* qe; int64_t ld_qe; int qe_stride_h; int rel_left, rel_right;  // qe[row][h * stride + clamp(j-i, -left, right) + left]
 };
@@ -81,10 +82,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 
   const int T = a.T;
   const float scale_log2e = a.scale_log2e;
-  int bid = blockIdx.x;
-  const int qb = bid % a.qblocks; bid /= a.qblocks;
-  const int h = bid % a.heads_q;
-  const int b = bid / a.heads_q;
+  // Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  All query blocks of one (sequence,
+  // head) pair read the same K / V (1.5 MiB at T = 1024, DH = 384): keep them on ONE XCD -- id % 8 picks the XCD, the ids that
+  // follow each other on that XCD walk the query blocks of one pair -- so K / V come from HBM once per pair instead of once
+  // per query block (the counters showed 6.8 GB fetched per launch for 0.8 GB of qkv).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int qb = slot % a.qblocks;
+  const int pair = (slot / a.qblocks) * 8 + xcd;
+  if (pair >= a.n_bh) return;   // grid is rounded up to whole groups of 8 pairs
+  const int h = pair % a.heads_q;
+  const int b = pair / a.heads_q;
   const int hk = h / a.group;
   const int64_t ld = a.ld_kv;
   const unsigned short* qbase = a.q + (int64_t)b * T * a.ld_q + (int64_t)h * DH;
@@ -302,7 +309,7 @@ int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, CAUSAL, RELKEY>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     attr_done = true;
   }
-  const int64_t nblocks = B * a.heads_q * a.qblocks;
+  const int64_t nblocks = (B * a.heads_q + 7) / 8 * 8 * a.qblocks;   // whole groups of 8 (sequence, head) pairs, one per XCD
   if (nblocks >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: grid too large"); return -1; }
   if ((int64_t)a.T * a.ld_kv >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: sequence too long for 32-bit offsets"); return -1; }
   hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, RELKEY>), dim3((unsigned)nblocks), dim3(512), C::SMEM, s, a);
@@ -338,6 +345,7 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
   a.T = (int)d->T; a.heads_q = d->heads_q; a.group = d->heads_q / d->heads_kv;
   a.scale_log2e = d->scale * 1.4426950408889634f;
   a.qblocks = (int)((d->T + 127) / 128);
+  a.n_bh = (int)(d->B * d->heads_q);
   a.qe = d->rel_qe; a.ld_qe = d->ld_rel_qe; a.qe_stride_h = d->rel_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
   hipStream_t s = (hipStream_t)stream;
   if (d->rel_qe) {
