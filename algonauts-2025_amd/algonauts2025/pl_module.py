@@ -22,69 +22,88 @@ from data_utils.dataloader import SegmentData
 
 
 class BrainModule(nn.Module):
+    """Same constructor arguments and hooks as the reference module; every tensor op below runs through the HIP kernels."""
+
+    STEP_NAMES = ("train", "val", "test")
+
     def __init__(self, model: nn.Module, loss: nn.Module, optim_config: tp.Any, metrics: dict[str, tp.Any],
                  max_epochs: int = 100, checkpoint_path: Path | None = None, config: dict[str, tp.Any] | None = None) -> None:
         super().__init__()
-        self.model = model
-        self.checkpoint_path = checkpoint_path
-        self.config = config
-        self.optim_config = optim_config
-        self.max_epochs = max_epochs
-        self.loss = loss
-        self.metrics = metrics
-        self.logged: dict[str, tp.Any] = {}
+        self.model, self.loss, self.metrics = model, loss, metrics
+        self.optim_config, self.max_epochs = optim_config, max_epochs
+        self.checkpoint_path, self.config = checkpoint_path, config
+        self.logged: dict[str, tp.Any] = {}   # what a Lightning logger would have received
 
+    # -- logging shims (Lightning provides these on a LightningModule) ---------------------------------
     def log(self, name: str, value: tp.Any, **kwargs: tp.Any) -> None:
         self.logged[name] = value
 
     def log_dict(self, values: dict[str, tp.Any], **kwargs: tp.Any) -> None:
         self.logged.update(values)
 
+    # -- the step ---------------------------------------------------------------------------------------------
     def forward(self, batch: SegmentData) -> torch.Tensor:
         return self.model(batch)
 
-    def _loss(self, y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
-        if hasattr(self.loss, "forward_bvt"):
-            return self.loss.forward_bvt(y_pred, y_true)
-        # foreign loss module: materialise the reference's "b d t -> (b t) d" flatten (pl_module.py:54-55)
-        V = y_pred.shape[1]
-        return self.loss(y_pred.permute(0, 2, 1).reshape(-1, V), y_true.permute(0, 2, 1).reshape(-1, V))
+    def _primary_loss(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """pl_module.py:54-56 without the two transposing copies when the loss understands [B, V, T'] directly."""
+        fused = getattr(self.loss, "forward_bvt", None)
+        if fused is not None:
+            return fused(pred, target)
+        n_out = pred.shape[1]   # foreign loss module: materialise the "b d t -> (b t) d" flatten it expects
+        return self.loss(pred.permute(0, 2, 1).reshape(-1, n_out), target.permute(0, 2, 1).reshape(-1, n_out))
+
+    def _alignment_term(self, batch: SegmentData, stage: str, n: int) -> torch.Tensor | float:
+        """pl_module.py:58-67: weight * mean of the per-modality InfoNCE terms (0 when the branch is off)."""
+        compute = getattr(self.model, "compute_contrastive_loss", None)
+        terms = compute(batch) if compute is not None else None
+        if not terms:
+            return 0.0
+        for modality, value in terms.items():
+            self.log(f"{stage}/contrastive/{modality}", value, batch_size=n)
+        weight = getattr(self.model.config, "contrastive_weight", 0.0)
+        return weight * (sum(terms.values()) / max(1, len(terms)))
+
+    def _feed_metrics(self, stage: str, pred: torch.Tensor, target: torch.Tensor, subjects: torch.Tensor) -> None:
+        """pl_module.py:70-105.  Grouped metrics take the sample's subject id (the reference repeats it T' times for the flattened
+        rows, :52); retrieval metrics see time-averaged inputs."""
+        for key, metric in self.metrics.items():
+            if not key.startswith(stage):
+                continue
+            if _is_grouped(metric):
+                metric.update(pred, target, groups=subjects)
+                continue
+            if "retrieval" in key:
+                metric.update(pred.mean(dim=-1), target.mean(dim=-1))
+            else:
+                metric.update(pred, target)
+            self.log(key, metric)
 
     def _run_step(self, batch: SegmentData, batch_idx: int, step_name: str):
-        y_true = batch.data["fmri"]  # B, D, T
-        y_pred = self.forward(batch)  # B, D, T
-        subject_id = batch.data["subject_id"]
-        loss = self._loss(y_pred, y_true.to(y_pred.dtype))
+        target = batch.data["fmri"]                 # [B, V, T']
+        pred = self.forward(batch)                  # [B, V, T']
+        n = pred.shape[0]
+        loss = self._primary_loss(pred, target.to(pred.dtype)) + self._alignment_term(batch, step_name, n)
+        self.log(f"{step_name}/loss", loss, batch_size=n)
+        self._feed_metrics(step_name, pred, target, batch.data["subject_id"])
+        return loss, pred.detach().cpu(), target.detach().cpu()
 
-        if hasattr(self.model, "compute_contrastive_loss"):
-            contrastive_losses = self.model.compute_contrastive_loss(batch)
-            if contrastive_losses:
-                weight = getattr(self.model.config, "contrastive_weight", 0.0)
-                total = 0.0
-                for name, c_loss in contrastive_losses.items():
-                    self.log(f"{step_name}/contrastive/{name}", c_loss, batch_size=y_pred.shape[0])
-                    total = total + c_loss
-                loss = loss + weight * (total / max(1, len(contrastive_losses)))
-        self.log(f"{step_name}/loss", loss, batch_size=y_pred.shape[0])
+    def training_step(self, batch: SegmentData, batch_idx: int):
+        """pl_module.py:126-128: returns the loss tensor; `loss.backward()` then runs the HIP backward kernels through
+        the autograd functions of modeling_utils/autograd.py (MSE / Pearson loss + optional InfoNCE alignment)."""
+        return self._run_step(batch, batch_idx, step_name="train")[0]
 
-        for metric_name, metric in self.metrics.items():
-            if not metric_name.startswith(step_name):
-                continue
-            if "grouped" in metric.__class__.__name__.lower():
-                # per-row groups of the flattened view == the sample's subject id repeated T' times (pl_module.py:52)
-                metric.update(y_pred, y_true, groups=subject_id)
-            else:
-                if "retrieval" in metric_name:
-                    metric.update(y_pred.mean(dim=-1), y_true.mean(dim=-1))
-                else:
-                    metric.update(y_pred, y_true)
-                self.log(metric_name, metric)
-        return loss, y_pred.detach().cpu(), y_true.detach().cpu()
+    def validation_step(self, batch: SegmentData, batch_idx: int):
+        return self._run_step(batch, batch_idx, step_name="val")[1:]
 
+    def test_step(self, batch: SegmentData, batch_idx: int):
+        return self._run_step(batch, batch_idx, step_name="test")[1:]
+
+    # -- epoch ends: grouped metrics report one value per subject ---------------------------------------------------
     def on_val_or_test_epoch_end(self, step_name: str) -> None:
-        for metric_name, metric in self.metrics.items():
-            if metric_name.startswith(step_name) and "grouped" in metric.__class__.__name__.lower():
-                self.log_dict({metric_name + "/" + k: v for k, v in metric.compute().items()})
+        for key, metric in self.metrics.items():
+            if key.startswith(step_name) and _is_grouped(metric):
+                self.log_dict({f"{key}/{group}": value for group, value in metric.compute().items()})
 
     def on_validation_epoch_end(self) -> None:
         self.on_val_or_test_epoch_end("val")
@@ -92,16 +111,18 @@ class BrainModule(nn.Module):
     def on_test_epoch_end(self) -> None:
         self.on_val_or_test_epoch_end("test")
 
-    def training_step(self, batch: SegmentData, batch_idx: int):
-        """pl_module.py:126-128: returns the loss tensor; `loss.backward()` then runs the HIP backward kernels through
-        the autograd functions of modeling_utils/autograd.py (MSE / Pearson loss + optional InfoNCE alignment)."""
-        loss, _, _ = self._run_step(batch, batch_idx, step_name="train")
-        return loss
+    def configure_optimizers(self, total_steps: int | None = None) -> tp.Any:
+        """pl_module.py:138-144: the optimiser over the trainable parameters.  An `optim_config` with a `build(params, total_steps=...)`
+        method (the reference's) is used as is; otherwise Adam(lr=1e-4) as in grids/defaults.py:126-133, as one HIP launch per
+        step (modeling_utils.optim.HipAdam)."""
+        params = [p for p in self.parameters() if p.requires_grad]
+        build = getattr(self.optim_config, "build", None)
+        if build is not None:
+            return build(params, total_steps=total_steps)
+        from modeling_utils.optim import HipAdam
 
-    def validation_step(self, batch: SegmentData, batch_idx: int):
-        _, y_pred, y_true = self._run_step(batch, batch_idx, step_name="val")
-        return y_pred, y_true
+        return HipAdam(params, lr=1e-4, weight_decay=0.0)
 
-    def test_step(self, batch: SegmentData, batch_idx: int):
-        _, y_pred, y_true = self._run_step(batch, batch_idx, step_name="test")
-        return y_pred, y_true
+
+def _is_grouped(metric: tp.Any) -> bool:
+    return "grouped" in type(metric).__name__.lower()
