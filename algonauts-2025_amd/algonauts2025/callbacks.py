@@ -53,9 +53,11 @@ class Benchmark:
     is a pickled dict and is only read when `trust_pickle=True` is passed explicitly (a `.json` of the same name is
     read without it)."""
 
+    SUBMISSION_NAME = "submission.npy"
+
     def __init__(self, root_data_dir: str | Path | None = None, target_sample_number: dict[str, dict[str, int]] | None = None,
                  trust_pickle: bool = False) -> None:
-        self.root_data_dir = Path(root_data_dir) if root_data_dir is not None else None
+        self.root_data_dir = None if root_data_dir is None else Path(root_data_dir)
         self.target_sample_number = target_sample_number
         self.trust_pickle = trust_pickle
         self.submission_dict: dict[str, dict[str, tp.Any]] = {}
@@ -63,48 +65,51 @@ class Benchmark:
     def on_test_epoch_start(self, trainer: tp.Any, pl_module: tp.Any) -> None:
         self.submission_dict = {}
 
-    def on_test_batch_end(self, trainer: tp.Any, pl_module: tp.Any, outputs: tp.Any, batch: tp.Any, batch_idx: int, dataloader_idx: int = 0) -> None:
-        y_pred, _ = outputs                                  # no ground truth on the test set
+    @staticmethod
+    def _time_major(y_pred: torch.Tensor) -> np.ndarray:
+        """[B, V, T'] predictions -> host array [B, T', V]: on the GPU one transposing launch + one copy for the whole batch."""
         if y_pred.is_cuda:
-            rows = ops.transpose_f32(y_pred.float().contiguous()).cpu().numpy()     # [B, T', V], one launch + one copy
-        else:                                                 # BrainModule.test_step already moved them (pl_module.py:107)
-            rows = np.ascontiguousarray(y_pred.float().numpy().transpose(0, 2, 1))
-        overlap_trs = 0   # callbacks.py:56 has 0.0, which makes :73 a TypeError under numpy >= 1.12; the windows do not overlap
-        for i, segment in enumerate(batch.segments):
+            return ops.transpose_f32(y_pred.float().contiguous()).cpu().numpy()
+        # BrainModule.test_step already moved them to the host (pl_module.py:107)
+        return np.ascontiguousarray(y_pred.float().numpy().transpose(0, 2, 1))
+
+    def on_test_batch_end(self, trainer: tp.Any, pl_module: tp.Any, outputs: tp.Any, batch: tp.Any, batch_idx: int, dataloader_idx: int = 0) -> None:
+        rows = self._time_major(outputs[0])       # outputs = (y_pred, y_true); there is no ground truth on the test set
+        # callbacks.py:56 sets the overlap between consecutive windows to 0.0 -- a float, which makes the slice at :73 a TypeError
+        # under numpy >= 1.12; the windows do not overlap (stride == duration), so the integer 0 is what the code means
+        overlap_trs = 0
+        for pred, segment in zip(rows, batch.segments):
             subject = _first_field(segment, "subject").split("/")[1]
             chunk = "s07" + _first_field(segment, "chunk").split(":")[1]
-            pred = rows[i]
-            per_subject = self.submission_dict.setdefault(subject, {})
-            if chunk not in per_subject:
-                per_subject[chunk] = []
-            else:
-                pred = pred[overlap_trs:]
-            per_subject[chunk].append(pred)
+            pieces = self.submission_dict.setdefault(subject, {}).setdefault(chunk, [])
+            pieces.append(pred[overlap_trs:] if pieces else pred)   # the first window of a chunk is kept whole
 
     def _samples(self, subject: str) -> dict[str, int]:
         if self.target_sample_number is not None:
             return self.target_sample_number[subject]
         if self.root_data_dir is None:
             raise ValueError("Benchmark needs target_sample_number or root_data_dir")
-        base = self.root_data_dir / f"algonauts_2025.competitors/fmri/{subject}/target_sample_number/{subject}_friends-s7_fmri_samples"
-        if base.with_suffix(".json").exists():
-            return {k: int(v) for k, v in json.loads(base.with_suffix(".json").read_text()).items()}
+        stem = self.root_data_dir / "algonauts_2025.competitors" / "fmri" / subject / "target_sample_number" / f"{subject}_friends-s7_fmri_samples"
+        as_json = stem.with_suffix(".json")
+        if as_json.exists():
+            return {chunk: int(n) for chunk, n in json.loads(as_json.read_text()).items()}
         if not self.trust_pickle:
-            raise ValueError(f"{base}.npy is a pickled dict; pass trust_pickle=True to read it, or give target_sample_number")
-        return np.load(base.with_suffix(".npy"), allow_pickle=True).item()
+            raise ValueError(f"{stem}.npy is a pickled dict; pass trust_pickle=True to read it, or give target_sample_number")
+        return np.load(stem.with_suffix(".npy"), allow_pickle=True).item()
 
     def on_test_epoch_end(self, trainer: tp.Any, pl_module: tp.Any) -> None:
-        for subject in self.submission_dict:
-            for chunk, sample_number in self._samples(subject).items():
-                result = np.concatenate(self.submission_dict[subject][chunk], axis=0)
-                if len(result) < sample_number:
-                    raise ValueError(f"Warning: {len(result)} predictions for {chunk} but expected at least {sample_number}")
-                self.submission_dict[subject][chunk] = result[:sample_number]
-        submission_path = Path(trainer.logger.save_dir) / "submission.npy"
-        np.save(submission_path, self.submission_dict)        # the competition's format: a pickled dict of arrays
+        for subject, chunks in self.submission_dict.items():
+            for chunk, wanted in self._samples(subject).items():
+                stacked = np.concatenate(chunks[chunk], axis=0)
+                if len(stacked) < wanted:
+                    raise ValueError(f"Warning: {len(stacked)} predictions for {chunk} but expected at least {wanted}")
+                chunks[chunk] = stacked[:wanted]
+        target = Path(trainer.logger.save_dir) / self.SUBMISSION_NAME
+        np.save(target, self.submission_dict)        # the competition's format: a pickled dict of arrays
+        archive = target.with_suffix(".zip")
         try:
-            with zipfile.ZipFile(submission_path.with_suffix(".zip"), "w") as zipf:
-                zipf.write(submission_path, arcname=submission_path.name)
-            print(f"Saved submission to {submission_path.with_suffix('.zip')}")
+            with zipfile.ZipFile(archive, "w") as zf:
+                zf.write(target, arcname=target.name)
+            print(f"Saved submission to {archive}")
         except Exception:
-            print(f"Failed to save submission to {submission_path.with_suffix('.zip')}")
+            print(f"Failed to save submission to {archive}")
