@@ -67,3 +67,96 @@ def allreduce_stats(stats: torch.Tensor, group: tp.Any = None) -> torch.Tensor:
     if ws > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
     return stats
+
+
+class GradReducer:
+    """Gradient averaging of the data-parallel training step: the job Lightning's DDP strategy does for the reference
+    (main.py:388-395, `ddp_find_unused_parameters_true`), laid out for xGMI.
+
+    * Gradients LIVE in a few large flat f32 buckets (`p.grad` is a view), filled in reverse registration order -- the order
+      backward produces them.  The default cap, 512 MiB, holds one encoder layer (113 M parameters = 453 MB): 8 + 1 buckets
+      for the 0.94 G-parameter model.  xGMI is point-to-point, a ring all-reduce is bound by one ≈153 GB/s link, so a
+      collective wants to be large (latency amortised) and there should be few of them; each still overlaps with the
+      backward of the layers below it.
+    * A post-accumulate hook counts a bucket's parameters down; complete buckets are all-reduced asynchronously (RCCL runs
+      them on its own stream) strictly IN BUCKET ORDER, and `finish()` launches whatever is left, so every rank issues the
+      same sequence of collectives even when modality dropout leaves different parameters unused on different ranks (their
+      gradient slices are simply zero).
+    * `zero_grad()` is one memset per bucket instead of one per tensor.
+    """
+
+    def __init__(self, params: tp.Iterable[torch.nn.Parameter], bucket_bytes: int = 512 << 20, group: tp.Any = None) -> None:
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradReducer: no trainable parameters")
+        if any(p.dtype != torch.float32 for p in self.params):
+            raise ValueError("GradReducer: parameters must be f32 (the residual stream and the optimiser state are)")
+        cap = max(1, bucket_bytes // 4)
+        plan: list[list[torch.nn.Parameter]] = [[]]
+        used = 0
+        for p in reversed(self.params):
+            if plan[-1] and used + p.numel() > cap:
+                plan.append([])
+                used = 0
+            plan[-1].append(p)
+            used += p.numel()
+        self.buckets: list[torch.Tensor] = []
+        self._views: list[list[tuple[torch.nn.Parameter, torch.Tensor]]] = []
+        self._bucket_of: dict[int, int] = {}
+        self._view_of: dict[int, torch.Tensor] = {}
+        for bi, members in enumerate(plan):
+            flat = torch.zeros(sum(p.numel() for p in members), dtype=torch.float32, device=members[0].device)
+            views, at = [], 0
+            for p in members:
+                views.append((p, flat[at:at + p.numel()].view_as(p)))
+                at += p.numel()
+                self._bucket_of[id(p)] = bi
+                self._view_of[id(p)] = views[-1][1]
+            self.buckets.append(flat)
+            self._views.append(views)
+        self._pending = [0] * len(plan)
+        self._next = 0                      # first bucket whose collective has not been issued in this step
+        self._works: list[tp.Any] = []
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.zero_grad()
+
+    # -- step protocol: zero_grad() -> backward -> finish() -> optimizer.step() --------------------------------------------
+    def zero_grad(self) -> None:
+        for flat, views in zip(self.buckets, self._views):
+            flat.zero_()
+            for p, v in views:
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+        self._pending = [len(v) for v in self._views]
+        self._next = 0
+        self._works = []
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        bi, view = self._bucket_of[id(p)], self._view_of[id(p)]
+        if p.grad.data_ptr() != view.data_ptr():                 # something replaced .grad (set_to_none): fold it back into the bucket
+            view.copy_(p.grad)
+            p.grad = view
+        self._pending[bi] -= 1
+        self._launch_ready()
+
+    def _launch_ready(self, force: bool = False) -> None:
+        _, ws = world()
+        while self._next < len(self.buckets) and (force or self._pending[self._next] <= 0):
+            if ws > 1:
+                flat = self.buckets[self._next]
+                flat.mul_(1.0 / ws)                                # pre-divide: SUM then equals the mean (gloo has no AVG)
+                self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._next += 1
+
+    def finish(self) -> None:
+        """Issue the collectives of buckets that never completed (unused parameters) and wait for all of them."""
+        self._launch_ready(force=True)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def remove(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []

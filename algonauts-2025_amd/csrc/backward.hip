@@ -359,6 +359,32 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const tribe_adam_tensor*
   }
 }
 
+// ---- running average of the weights (Lightning StochasticWeightAveraging / torch.optim.swa_utils.AveragedModel's default avg_fn:
+// avg += (p - avg) / (n_averaged + 1); main.py:365-373).  Same table / work list as Adam: t.p = the average (updated), t.g = the live
+// parameter (read); m, v unused.  HBM-bound: 8 B read + 4 B written per parameter.  weight == 1 is a plain copy (first average).
+__global__ __launch_bounds__(256) void swa_update_kernel(const tribe_adam_tensor* __restrict__ table, const int32_t* __restrict__ chunk_tensor,
+                                                         const int64_t* __restrict__ chunk_start, float weight) {
+  const tribe_adam_tensor t = table[chunk_tensor[blockIdx.x]];
+  const int64_t i0 = chunk_start[blockIdx.x];
+  const int64_t i1 = (i0 + ADAM_CHUNK < t.n) ? i0 + ADAM_CHUNK : t.n;
+  const bool copy = weight == 1.f;
+  auto blend = [&](float a, float p) { return copy ? p : a + (p - a) * weight; };
+  const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g) & 15) == 0 && (i0 & 3) == 0;
+  int64_t done = i0;
+  if (vec) {
+    const int64_t n4 = (i1 - i0) / 4;
+    for (int64_t q = threadIdx.x; q < n4; q += 256) {
+      const int64_t i = i0 + 4 * q;
+      float4 a = *(float4*)(t.p + i);
+      const float4 p = *(const float4*)(t.g + i);
+      a.x = blend(a.x, p.x); a.y = blend(a.y, p.y); a.z = blend(a.z, p.z); a.w = blend(a.w, p.w);
+      *(float4*)(t.p + i) = a;
+    }
+    done = i0 + 4 * n4;
+  }
+  for (int64_t i = done + threadIdx.x; i < i1; i += 256) t.p[i] = blend(t.p[i], t.g[i]);
+}
+
 }  // namespace
 
 int tribe_internal_softmax(const float* S, int64_t R, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p, hipStream_t stream);
@@ -530,6 +556,16 @@ extern "C" int tribe_transpose_bf16_b2(const void* in, int32_t in_dtype, int64_t
   if (in_dtype == TRIBE_F32) { if (vec) TRIBE_TR(float, 4); else TRIBE_TR(float, 1); }
   else { if (vec) TRIBE_TR(unsigned short, 4); else TRIBE_TR(unsigned short, 1); }
 #undef TRIBE_TR
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_swa_update(const tribe_adam_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks,
+                                float weight, void* stream) {
+  TRIBE_REQUIRE(table && chunk_tensor && chunk_start, "tribe_swa_update: null pointer");
+  TRIBE_REQUIRE(n_chunks > 0 && n_chunks < (1ll << 31), "tribe_swa_update: need 1 .. 2^31 chunks");
+  TRIBE_REQUIRE(weight > 0.f && weight <= 1.f, "tribe_swa_update: weight = 1 / (n_averaged + 1) must lie in (0, 1]");
+  hipLaunchKernelGGL(swa_update_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_start, weight);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

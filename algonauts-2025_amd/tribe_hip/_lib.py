@@ -213,6 +213,7 @@ SIGNATURES = {
     "tribe_rownorm_scale_fwd": (C.c_int, [vp, i64, i64, vp, f32, f32, vp, vp]),
     "tribe_adam_chunk_elems": (i64, []),
     "tribe_adam_step": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, i32, vp]),
+    "tribe_swa_update": (C.c_int, [vp, vp, vp, i64, f32, vp]),
     "tribe_quantize_fp8_fwd": (C.c_int, [vp, i32, i64, i64, i64, f32, vp, i64, vp]),
     "tribe_absmax_fwd": (C.c_int, [vp, i32, i64, i64, i64, vp, i32, vp]),
     "tribe_weighted_sum_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp]),

@@ -506,6 +506,12 @@ typedef struct tribe_adam_tensor {
 int64_t tribe_adam_chunk_elems(void);
 int tribe_adam_step(const tribe_adam_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int64_t step, int32_t decoupled, void* stream);
+/* Running weight average of the reference's StochasticWeightAveraging callback (algonauts2025/main.py:365-373; the averaging rule is
+ * torch.optim.swa_utils.AveragedModel's default: avg += (p - avg) * weight with weight = 1 / (n_averaged + 1), weight 1 = copy).
+ * Same table and work list as tribe_adam_step: table[i].p = the average (updated in place), table[i].g = the live parameter;
+ * m and v are not touched and may be NULL. */
+int tribe_swa_update(const tribe_adam_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, float weight,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -154,3 +154,90 @@ def test_replica_scheduling_two_ranks_and_grid_expansion():
     out = results[0][3]
     assert [o["seed"] for o in out] == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4] and [o["rank"] for o in out] == [0, 1] * 5
     assert [o["n_layers"] for o in out] == [3, 2] * 5
+
+
+def _reducer_worker(rank: int, world: int, port: int, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from algonauts2025.distributed import GradReducer
+
+        torch.manual_seed(0)                                     # same weights on every rank
+        net = torch.nn.ModuleDict({"a": torch.nn.Linear(12, 16), "b": torch.nn.Linear(16, 16), "side": torch.nn.Linear(16, 16),
+                                   "c": torch.nn.Linear(16, 3)})
+        x = torch.randn(8, 12, generator=torch.Generator().manual_seed(1))
+        y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+
+        def loss_of(xb, yb, use_side):
+            h = torch.relu(net["b"](torch.relu(net["a"](xb))))
+            if use_side:
+                h = h + net["side"](h)
+            return ((net["c"](h) - yb) ** 2).mean()
+
+        # single-process truth: mean over ranks of the per-rank losses (rank 1 skips the side branch, as modality dropout might)
+        want = torch.autograd.grad((loss_of(x[0::2], y[0::2], True) + loss_of(x[1::2], y[1::2], False)) / 2, list(net.parameters()),
+                                   allow_unused=True)
+        reducer = GradReducer(net.parameters(), bucket_bytes=4 * 300)      # several small buckets, 'side' in the middle of one
+        ok = len(reducer.buckets) >= 3
+        for step in range(2):                                    # twice: zero_grad must restore the bucket views and the counters
+            reducer.zero_grad()
+            loss_of(x[rank::2], y[rank::2], use_side=(rank == 0)).backward()
+            reducer.finish()
+            for p, w in zip(net.parameters(), want):
+                w = torch.zeros_like(p) if w is None else w
+                ok = ok and bool(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7)) and p.grad.data_ptr() == reducer._view_of[id(p)].data_ptr()
+        # an optimizer.zero_grad(set_to_none=True) in between is tolerated: the hook folds the fresh gradient back into its bucket
+        reducer.zero_grad()
+        for p in net.parameters():
+            p.grad = None
+        loss_of(x[rank::2], y[rank::2], use_side=(rank == 0)).backward()
+        reducer.finish()
+        side_w = net["side"].weight
+        ok = ok and bool(torch.allclose(net["a"].weight.grad, want[0], rtol=1e-5, atol=1e-7))
+        if rank == 1:                                            # never produced here, not re-attached either: the bucket slice carries rank 0's half
+            ok = ok and side_w.grad is None and bool(torch.allclose(reducer._view_of[id(side_w)], want[4], rtol=1e-5, atol=1e-7))
+        reducer.remove()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks_matches_single_process_and_tolerates_unused_parameters():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)], results
+
+
+def test_optimizer_configs_mirror_the_reference_block():
+    """grids/defaults.py:126-141 `optim` block through modeling_utils.optimizers (base.py:25-96): validation and what gets built."""
+    import pydantic
+
+    from modeling_utils.optimizers import LightningOptimizerConfig, TorchOptimizerConfig
+
+    block = {"optimizer": {"name": "Adam", "lr": 1e-4, "kwargs": {"weight_decay": 0.0}},
+             "scheduler": {"name": "OneCycleLR", "kwargs": {"max_lr": 1e-4, "pct_start": 0.1}}}
+    cfg = LightningOptimizerConfig(**block)
+    assert cfg.name == "LightningOptimizer" and cfg.interval == "step"
+    params = [torch.nn.Parameter(torch.zeros(4))]
+    built = cfg.build(params, total_steps=50)
+    assert isinstance(built["optimizer"], torch.optim.Adam)                 # CPU parameters: torch's own (HipAdam needs GPU tensors)
+    sched = built["lr_scheduler"]
+    assert isinstance(sched["scheduler"], torch.optim.lr_scheduler.OneCycleLR) and sched["interval"] == "step"
+    assert sched["scheduler"].total_steps == 50
+    assert "lr_scheduler" not in LightningOptimizerConfig(optimizer=block["optimizer"]).build(params)
+    assert isinstance(TorchOptimizerConfig(name="SGD", lr=0.1, kwargs={"momentum": 0.9}).build(params), torch.optim.SGD)
+    for bad in ({"optimizer": {"name": "Adam", "lr": 1e-4, "kwargs": {"lr": 1.0}}},
+                {"optimizer": {"name": "NoSuchOptimizer", "lr": 1e-4}},
+                {"optimizer": {"name": "Adam", "lr": 1e-4, "kwargs": {"not_an_argument": 1}}},
+                {"optimizer": {"name": "Adam", "lr": 1e-4}, "scheduler": {"name": "OneCycleLR", "kwargs": {"pct_start": 0.1}}},   # max_lr missing
+                {"optimizer": {"name": "Adam", "lr": 1e-4}, "extra_field": 1}):
+        with pytest.raises(pydantic.ValidationError):
+            LightningOptimizerConfig(**bad)

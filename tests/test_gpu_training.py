@@ -227,3 +227,130 @@ def test_transpose_bf16_vector_and_scalar_paths(Z, R, Cc, pad_c, dtype):
     assert got.shape == (Z, Cc, Rp)
     want = full[:, :, :Cc].to(torch.bfloat16).transpose(1, 2)
     assert torch.equal(got[:, :, :R], want) and not got[:, :, R:].any()
+
+
+def test_swa_update_matches_averaged_model_rule():
+    """tribe_swa_update against torch.optim.swa_utils.AveragedModel (CPU): ragged sizes, four updates, then the copy-back."""
+    from torch.optim.swa_utils import AveragedModel
+
+    from algonauts2025.callbacks import StochasticWeightAveraging
+
+    class Bag(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(s, generator=g)) for s in [(3072, 129), (5,), (16385,), (2, 1024, 9)]])
+
+    ref, mine = Bag(), Bag().cuda()
+    avg_ref = AveragedModel(ref)
+    swa = StochasticWeightAveraging(swa_lrs=1e-5, swa_epoch_start=0.6, annealing_epochs=2)
+    g = torch.Generator().manual_seed(4)
+    for n in range(4):
+        with torch.no_grad():
+            for a, b in zip(ref.ps, mine.ps):
+                d = torch.randn(a.shape, generator=g)
+                a.add_(d), b.add_(d.cuda())
+        avg_ref.update_parameters(ref)
+        swa.update_average(mine)
+        assert swa.n_averaged == n + 1 == int(avg_ref.n_averaged)
+        for a, b in zip(avg_ref.module.ps, swa.averages):
+            torch.testing.assert_close(b.cpu(), a.detach(), rtol=1e-6, atol=1e-6)
+    with pytest.raises(Exception):
+        StochasticWeightAveraging(swa_lrs=1e-5).update_average(Bag())            # CPU parameters: no fallback
+
+
+def test_fit_loop_onecycle_then_swa():
+    """Trainer.fit with the reference's optimiser block (defaults.py:126-141) and SWA settings (main.py:365-373) on a small model:
+    the LR trajectory is torch's OneCycleLR per step, then SWALR per epoch from int(0.6 * n_epochs); the final weights are the mean
+    of the weights seen at the start of the averaged epochs; the loss goes down."""
+    from torch.optim.swa_utils import SWALR
+
+    from algonauts2025.callbacks import StochasticWeightAveraging
+    from algonauts2025.model import FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from algonauts2025.trainer import Trainer
+    from data_utils.dataloader import SegmentData
+    from modeling_utils.losses import TorchLossConfig
+    from modeling_utils.optim import HipAdam
+    from modeling_utils.optimizers import LightningOptimizerConfig
+
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    V, Tout, S, B, T = 50, 10, 3, 4, 31
+    n_epochs, n_batches = 5, 3
+    model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=1, heads=4, modality_dropout=0.0).build(fdims, V, Tout)
+    optim = LightningOptimizerConfig(optimizer={"name": "Adam", "lr": 1e-4, "kwargs": {"weight_decay": 0.0}},
+                                     scheduler={"name": "OneCycleLR", "kwargs": {"max_lr": 1e-3, "pct_start": 0.1}})
+    bm = BrainModule(model, TorchLossConfig(name="MSELoss").build(), optim, {}, max_epochs=n_epochs)
+    batches = []
+    for i in range(n_batches):
+        data = tribe_ref.synthetic_batch(B, T, fdims, S, seed=20 + i)
+        fmri = torch.randn(B, V, Tout, generator=torch.Generator().manual_seed(30 + i))
+        batches.append(SegmentData(data={**data, "fmri": fmri}, segments=[None] * B))
+
+    class Probe:                                                 # after the SWA callback in the list: sees what it averaged
+        def __init__(self):
+            self.lrs, self.snaps = [], {}
+
+        def on_train_epoch_start(self, trainer, module):
+            self.lrs.append(trainer.optimizers[0].param_groups[0]["lr"])
+            self.snaps[trainer.current_epoch] = [p.detach().clone() for p in module.parameters()]
+
+    annealing = int(n_epochs * (1 - 0.6))
+    swa = StochasticWeightAveraging(swa_epoch_start=0.6, annealing_epochs=annealing, swa_lrs=1e-5, annealing_strategy="cos")
+    probe = Probe()
+    trainer = Trainer(max_epochs=n_epochs, callbacks=[swa, probe])
+    trainer.fit(bm, batches)
+    assert isinstance(trainer.optimizers[0], HipAdam)
+    assert (swa.swa_start, swa.swa_end, swa.n_averaged) == (3, 4, 2)
+
+    # the same schedule on a dummy torch optimiser
+    dummy = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sched = {"s": torch.optim.lr_scheduler.OneCycleLR(dummy, max_lr=1e-3, pct_start=0.1, total_steps=n_epochs * n_batches), "per": "step"}
+    want_lrs = []
+    for epoch in range(n_epochs):
+        if epoch == 3:
+            sched = {"s": SWALR(dummy, swa_lr=1e-5, anneal_epochs=annealing, anneal_strategy="cos"), "per": "epoch"}
+        want_lrs.append(dummy.param_groups[0]["lr"])
+        for _ in range(n_batches):
+            dummy.step()
+            if sched["per"] == "step":
+                sched["s"].step()
+        if sched["per"] == "epoch":
+            sched["s"].step()
+    assert probe.lrs == pytest.approx(want_lrs, rel=1e-12)
+    for p, a, b in zip(bm.parameters(), probe.snaps[3], probe.snaps[4]):
+        torch.testing.assert_close(p.detach(), (a + b) / 2, rtol=1e-6, atol=1e-7)
+    losses = [h["train/loss"] for h in trainer.history]
+    assert losses[2] < losses[0], losses
+    # the averaged weights are what the next forward uses (packed-weight caches refreshed through the version counters)
+    bm.eval()
+    with torch.no_grad():
+        again = bm(batches[0].to("cuda"))
+    assert torch.isfinite(again).all()
+
+
+def test_fit_with_bucketed_gradients_equals_plain_fit():
+    """GradReducer on the GPU (world of one: no collective, but gradients live in the flat buckets, HipAdam steps from the views and
+    zero_grad is a memset per bucket): same weights as the plain loop up to the atomics' summation order."""
+    from algonauts2025.model import FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from algonauts2025.trainer import Trainer
+    from data_utils.dataloader import SegmentData
+    from modeling_utils.losses import TorchLossConfig
+
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    V, Tout, S, B, T = 50, 10, 3, 4, 31
+    batches = []
+    for i in range(2):
+        data = tribe_ref.synthetic_batch(B, T, fdims, S, seed=40 + i)
+        batches.append(SegmentData(data={**data, "fmri": torch.randn(B, V, Tout, generator=torch.Generator().manual_seed(50 + i))}, segments=[None] * B))
+    finals = []
+    for bucketed in (False, True):
+        torch.manual_seed(7)
+        model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=2, heads=4, contrastive_enabled=True).build(fdims, V, Tout)
+        bm = BrainModule(model, TorchLossConfig(name="MSELoss").build(), None, {})
+        trainer = Trainer(max_epochs=2, reduce_gradients=bucketed, bucket_bytes=8 << 20)
+        trainer.fit(bm, batches)
+        finals.append([p.detach().cpu() for p in bm.parameters()])
+    for a, b in zip(*finals):
+        assert _rel(b, a) < 1e-4
