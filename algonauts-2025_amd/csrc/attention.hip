@@ -219,16 +219,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
           s1[r] += qrow_e[d1];
         }
       }
+      // sv keeps the RAW scores: the softmax scale rides in the exponent's fma below (scale > 0, so the maximum commutes with it).
+      // Only a sub-tile that crosses the end of the sequence or the causal diagonal of this wave's rows pays for masking
+      // (wave-uniform test; the per-element compare + select was a quarter of the loop's vector instructions at DH = 64).
+      const bool edge = sub_key0 + 32 > T || (CAUSAL && sub_key0 + 31 > q0);
+      if (edge) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sv[u][r] = (key_base + r < lim) ? s0[r] * scale_log2e : -INFINITY;
-        sv[u][4 + r] = (key_base + 16 + r < lim) ? s1[r] * scale_log2e : -INFINITY;
-        pmax = fmaxf(pmax, fmaxf(sv[u][r], sv[u][4 + r]));
+        for (int r = 0; r < 4; ++r) {
+          sv[u][r] = (key_base + r < lim) ? s0[r] : -INFINITY;
+          sv[u][4 + r] = (key_base + 16 + r < lim) ? s1[r] : -INFINITY;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sv[u][r] = s0[r]; sv[u][4 + r] = s1[r]; }
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pmax = fmaxf(pmax, fmaxf(sv[u][r], sv[u][4 + r]));
     }
     // the other three 16-lane groups hold the other keys of this query
     pmax = fmaxf(pmax, __shfl_xor(pmax, 16, 64));
     pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+    pmax *= scale_log2e;
     // deferred max: rescale only when some row's maximum moved by more than 2^8
     if (!__all(pmax - m_run <= 8.0f)) {
       const float m_new = fmaxf(m_run, pmax);
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     for (int u = 0; u < C::NSUB; ++u)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float p = __builtin_amdgcn_exp2f(sv[u][j] - m_run);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sv[u][j], scale_log2e, -m_run));
         psum += p;
         pf[u][j] = (short)f32_to_bf16(p);
       }
