@@ -196,12 +196,13 @@ __global__ __launch_bounds__(256) void rotary_kernel(unsigned short* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
-// RMSNorm / LayerNorm: one wave per row (f32 in, f32 statistics), bf16 or f32 out
+// RMSNorm / LayerNorm: one wave per row (f32 in, f32 statistics), bf16 or f32 out; OUT_BF16 == 2: e4m3 bytes of the
+// bf16-rounded result times q_inv_scale, saturating (= the bf16 norm followed by tribe_quantize_fp8_fwd, bit for bit, in one pass)
 // ---------------------------------------------------------------------------------
 template <int OUT_BF16, int LAYERNORM>
 __global__ __launch_bounds__(256) void rowstat_norm_kernel(const float* __restrict__ x, int64_t rows, int64_t dim,
                                                            const float* __restrict__ w, const float* __restrict__ b, float eps,
-                                                           void* __restrict__ y) {
+                                                           void* __restrict__ y, float q_inv_scale = 0.f) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -237,7 +238,14 @@ __global__ __launch_bounds__(256) void rowstat_norm_kernel(const float* __restri
       const float4 bb = ((const float4*)b)[i];
       o0 += bb.x; o1 += bb.y; o2 += bb.z; o3 += bb.w;
     }
-    if (OUT_BF16) {
+    if (OUT_BF16 == 2) {
+      float q[4] = {o0, o1, o2, o3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = fminf(fmaxf(bf16_to_f32(f32_to_bf16(q[j])) * q_inv_scale, -448.f), 448.f);
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], pk, true);
+      ((int*)((unsigned char*)y + row * dim))[i] = pk;
+    } else if (OUT_BF16) {
       u16x4_t o;
       o[0] = f32_to_bf16(o0); o[1] = f32_to_bf16(o1); o[2] = f32_to_bf16(o2); o[3] = f32_to_bf16(o3);
       ((u16x4_t*)((unsigned short*)y + row * dim))[i] = o;
@@ -559,9 +567,26 @@ extern "C" int tribe_rmsnorm_fwd(const float* x, int64_t rows, int64_t dim, cons
   TRIBE_REQUIRE(y_dtype == TRIBE_F32 || y_dtype == TRIBE_BF16, "tribe_rmsnorm_fwd: y_dtype must be f32 or bf16");
   dim3 grid((unsigned)((rows + 3) / 4));
   if (y_dtype == TRIBE_BF16)
-    hipLaunchKernelGGL((rowstat_norm_kernel<1, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, (const float*)nullptr, eps, y);
+    hipLaunchKernelGGL((rowstat_norm_kernel<1, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, (const float*)nullptr, eps, y, 0.f);
   else
-    hipLaunchKernelGGL((rowstat_norm_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, (const float*)nullptr, eps, y);
+    hipLaunchKernelGGL((rowstat_norm_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, (const float*)nullptr, eps, y, 0.f);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_norm_quantize_fp8_fwd(const float* x, int64_t rows, int64_t dim, const float* w, const float* b, int32_t layernorm,
+                                           float eps, float inv_scale, uint8_t* y8, void* stream) {
+  TRIBE_REQUIRE(x && w && y8, "tribe_norm_quantize_fp8_fwd: null pointer");
+  TRIBE_REQUIRE(rows > 0 && dim > 0 && dim % 16 == 0, "tribe_norm_quantize_fp8_fwd: rows=%lld dim=%lld (dim %% 16 required: the e4m3 GEMM's K)",
+                (long long)rows, (long long)dim);
+  TRIBE_REQUIRE(inv_scale > 0.f && ((uintptr_t)y8 % 4) == 0 && (layernorm || !b),
+                "tribe_norm_quantize_fp8_fwd: inv_scale must be positive, y8 4-byte aligned, and RMSNorm takes no bias");
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (layernorm)
+    hipLaunchKernelGGL((rowstat_norm_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, b, eps, (void*)y8, inv_scale);
+  else
+    hipLaunchKernelGGL((rowstat_norm_kernel<2, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, (const float*)nullptr, eps, (void*)y8,
+                       inv_scale);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }
@@ -574,9 +599,9 @@ extern "C" int tribe_layernorm_fwd(const float* x, int64_t rows, int64_t dim, co
   TRIBE_REQUIRE(y_dtype == TRIBE_F32 || y_dtype == TRIBE_BF16, "tribe_layernorm_fwd: y_dtype must be f32 or bf16");
   dim3 grid((unsigned)((rows + 3) / 4));
   if (y_dtype == TRIBE_BF16)
-    hipLaunchKernelGGL((rowstat_norm_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, b, eps, y);
+    hipLaunchKernelGGL((rowstat_norm_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, b, eps, y, 0.f);
   else
-    hipLaunchKernelGGL((rowstat_norm_kernel<0, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, b, eps, y);
+    hipLaunchKernelGGL((rowstat_norm_kernel<0, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, rows, dim, w, b, eps, y, 0.f);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

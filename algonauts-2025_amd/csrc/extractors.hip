@@ -51,8 +51,20 @@ struct Fp8Linear4 {
 };
 static_assert(sizeof(Fp8Linear4) == sizeof(tribe_llama_fp8_layer) && sizeof(Fp8Linear4) == sizeof(tribe_vit_fp8_layer), "fp8 layer layouts");
 
+// fp8 route of the pre-norms: the norm writes the e4m3 operand of the Linear that follows straight into the staging buffer (one pass
+// over x instead of norm -> bf16 -> quantise).  *done tells the caller whether it did; otherwise the bf16 norm must run.
+inline int extractor_norm_fp8(const void* fp8_layers, int layer, int which, const float* x, int64_t rows, int64_t dim, const float* w,
+                              const float* b, int layernorm, float eps, uint8_t* q8, void* stream, bool* done) {
+  *done = false;
+  if (!fp8_layers) return 0;
+  const float in_scale = ((const Fp8Linear4*)fp8_layers)[layer].in_scale[which];
+  if (!(in_scale > 0.f)) return 0;   // extractor_linear reports the missing scale
+  *done = true;
+  return tribe_norm_quantize_fp8_fwd(x, rows, dim, w, b, layernorm, eps, 1.0f / in_scale, q8, stream);
+}
+
 inline int extractor_linear(const char* who, const void* fp8_layers, float* amax_out, int layer, int which, tribe_gemm_desc& g,
-                            const void* w_bf16, uint8_t* q8, void* stream) {
+                            const void* w_bf16, uint8_t* q8, void* stream, bool a_is_q8 = false) {
   if (amax_out) {
     int rc = tribe_absmax_fwd(g.A, TRIBE_BF16, g.M, g.K, g.lda, amax_out + (int64_t)layer * 4 + which, 1, stream);
     if (rc) return rc;
@@ -64,8 +76,10 @@ inline int extractor_linear(const char* who, const void* fp8_layers, float* amax
   const Fp8Linear4& F = ((const Fp8Linear4*)fp8_layers)[layer];
   TRIBE_REQUIRE(F.w[which] && F.in_scale[which] > 0.f && F.w_scale[which] > 0.f, "%s: layer %d fp8 weight %d or its scales missing", who, layer,
                 which);
-  int rc = tribe_quantize_fp8_fwd(g.A, TRIBE_BF16, g.M, g.K, g.lda, 1.0f / F.in_scale[which], q8, g.K, stream);
-  if (rc) return rc;
+  if (!a_is_q8) {
+    int rc = tribe_quantize_fp8_fwd(g.A, TRIBE_BF16, g.M, g.K, g.lda, 1.0f / F.in_scale[which], q8, g.K, stream);
+    if (rc) return rc;
+  }
   g.A = q8;
   g.B = F.w[which];
   g.alpha = F.in_scale[which] * F.w_scale[which];
@@ -113,13 +127,15 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
     const tribe_llama_layer& L = d->layers_host[l];
     TRIBE_REQUIRE(L.input_norm_w && L.w_qkv && L.w_o && L.post_norm_w && L.w_gate_up && L.w_down,
                   "tribe_llama_fwd: layer %d has a null parameter", l);
-    rc = tribe_rmsnorm_fwd(x, M, dim, L.input_norm_w, d->rms_eps, xn, TRIBE_BF16, stream);
+    bool q_in = false;
+    rc = extractor_norm_fp8(d->fp8_host, l, 0, x, M, dim, L.input_norm_w, nullptr, 0, d->rms_eps, q8, stream, &q_in);
+    if (!rc && !q_in) rc = tribe_rmsnorm_fwd(x, M, dim, L.input_norm_w, d->rms_eps, xn, TRIBE_BF16, stream);
     if (rc) return rc;
     tribe_gemm_desc g = gemm_zero();
     g.M = M; g.N = p.qkv_w; g.K = dim;
     g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = qkv; g.ldc = p.qkv_w; g.c_dtype = TRIBE_BF16; g.role = TRIBE_ROLE_QKV;
-    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 0, g, L.w_qkv, q8, stream);
+    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 0, g, L.w_qkv, q8, stream, q_in);
     if (rc) return rc;
     // rotate_half rotary over the full head dim on the q heads and the k heads (adjacent in the fused row)
     rc = tribe_rotary_fwd(qkv, M, d->T, p.qkv_w, d->heads_q + d->heads_kv, d->dim_head, d->dim_head, d->cos_tab, d->sin_tab, 0, stream);
@@ -140,13 +156,14 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32; g.res = x; g.ldres = dim; g.role = TRIBE_ROLE_OUT_PROJ;
     rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 1, g, L.w_o, q8, stream);
     if (rc) return rc;
-    rc = tribe_rmsnorm_fwd(x, M, dim, L.post_norm_w, d->rms_eps, xn, TRIBE_BF16, stream);
+    rc = extractor_norm_fp8(d->fp8_host, l, 2, x, M, dim, L.post_norm_w, nullptr, 0, d->rms_eps, q8, stream, &q_in);
+    if (!rc && !q_in) rc = tribe_rmsnorm_fwd(x, M, dim, L.post_norm_w, d->rms_eps, xn, TRIBE_BF16, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = 2 * (int64_t)d->inter; g.K = dim;
     g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = act; g.ldc = d->inter; g.c_dtype = TRIBE_BF16; g.act = TRIBE_ACT_SWIGLU; g.role = TRIBE_ROLE_FF1;
-    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 2, g, L.w_gate_up, q8, stream);
+    rc = extractor_linear("tribe_llama_fwd", d->fp8_host, d->amax_out, l, 2, g, L.w_gate_up, q8, stream, q_in);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = dim; g.K = d->inter;
@@ -238,14 +255,16 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
   for (int l = 0; l < d->depth; ++l) {
     const tribe_vit_layer& L = d->layers_host[l];
     TRIBE_REQUIRE(L.norm1_w && L.w_qkv && L.w_proj && L.norm2_w && L.w_fc1 && L.w_fc2, "tribe_vjepa2_fwd: layer %d has a null parameter", l);
-    rc = tribe_layernorm_fwd(x, M, dim, L.norm1_w, L.norm1_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    bool q_in = false;
+    rc = extractor_norm_fp8(d->fp8_host, l, 0, x, M, dim, L.norm1_w, L.norm1_b, 1, d->ln_eps, q8, stream, &q_in);
+    if (!rc && !q_in) rc = tribe_layernorm_fwd(x, M, dim, L.norm1_w, L.norm1_b, d->ln_eps, xn, TRIBE_BF16, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = 3 * dim; g.K = dim;
     g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = qkv; g.ldc = 3 * dim; g.c_dtype = TRIBE_BF16; g.role = TRIBE_ROLE_QKV;
     if (L.b_qkv) { g.bias = L.b_qkv; g.bias_mode = TRIBE_BIAS_COL; }
-    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 0, g, L.w_qkv, q8, stream);
+    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 0, g, L.w_qkv, q8, stream, q_in);
     if (rc) return rc;
     rc = tribe_rotary_fwd(qkv, M, p.tokens, 3 * dim, 2 * d->heads, d->dim_head, d->dim_head, d->cos_tab, d->sin_tab, 2, stream);
     if (rc) return rc;
@@ -265,14 +284,15 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
     if (L.b_proj) { g.bias = L.b_proj; g.bias_mode = TRIBE_BIAS_COL; }
     rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 1, g, L.w_proj, q8, stream);
     if (rc) return rc;
-    rc = tribe_layernorm_fwd(x, M, dim, L.norm2_w, L.norm2_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    rc = extractor_norm_fp8(d->fp8_host, l, 2, x, M, dim, L.norm2_w, L.norm2_b, 1, d->ln_eps, q8, stream, &q_in);
+    if (!rc && !q_in) rc = tribe_layernorm_fwd(x, M, dim, L.norm2_w, L.norm2_b, d->ln_eps, xn, TRIBE_BF16, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = d->mlp; g.K = dim;
     g.A = xn; g.lda = dim; g.ldb = dim;
     g.C = act; g.ldc = d->mlp; g.c_dtype = TRIBE_BF16; g.act = TRIBE_ACT_GELU; g.role = TRIBE_ROLE_FF1;
     if (L.b_fc1) { g.bias = L.b_fc1; g.bias_mode = TRIBE_BIAS_COL; }
-    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 2, g, L.w_fc1, q8, stream);
+    rc = extractor_linear("tribe_vjepa2_fwd", d->fp8_host, d->amax_out, l, 2, g, L.w_fc1, q8, stream, q_in);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = dim; g.K = d->mlp;

@@ -215,6 +215,7 @@ SIGNATURES = {
     "tribe_adam_step": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, i32, vp]),
     "tribe_swa_update": (C.c_int, [vp, vp, vp, i64, f32, vp]),
     "tribe_quantize_fp8_fwd": (C.c_int, [vp, i32, i64, i64, i64, f32, vp, i64, vp]),
+    "tribe_norm_quantize_fp8_fwd": (C.c_int, [vp, i64, i64, vp, vp, i32, f32, f32, vp, vp]),
     "tribe_absmax_fwd": (C.c_int, [vp, i32, i64, i64, i64, vp, i32, vp]),
     "tribe_weighted_sum_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp]),
     "tribe_corr_matrix_workspace_bytes": (sz, [i64]),

@@ -565,6 +565,20 @@ def quantize_fp8(x: torch.Tensor, scale: float, K_pad: int | None = None) -> tor
     return out
 
 
+def norm_quantize_fp8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, eps: float, scale: float, layernorm: bool) -> torch.Tensor:
+    """quantize_fp8(rmsnorm(x) | layernorm(x) in bf16, scale) in one pass: x f32 [..., dim] -> uint8 [rows, dim] of e4m3 bytes."""
+    _cuda(x, torch.float32, "x")
+    _cuda(w, torch.float32, "w")
+    if not scale > 0:
+        raise ValueError(f"norm_quantize_fp8: scale must be positive, got {scale}")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    out = torch.empty(rows, dim, dtype=torch.uint8, device=x.device)
+    check(lib().tribe_norm_quantize_fp8_fwd(x.data_ptr(), rows, dim, w.data_ptr(), _p(b), int(layernorm), eps, 1.0 / scale, out.data_ptr(),
+                                            _stream()), "tribe_norm_quantize_fp8_fwd")
+    return out
+
+
 def gemm_fp8_nt(a: torch.Tensor, b: torch.Tensor, alpha: float, *, bias: torch.Tensor | None = None, act: str | None = None,
                 res: torch.Tensor | None = None, out_dtype: torch.dtype = torch.float32, out: torch.Tensor | None = None) -> torch.Tensor:
     """out[m, n] = epi(alpha * sum_k a[m, k] * b[n, k]) with a, b uint8 tensors of e4m3 bytes ([M, K], [N, K], K % 128 == 0)."""

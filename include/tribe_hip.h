@@ -492,6 +492,12 @@ int tribe_gemm_fp8(const tribe_gemm_desc* d, void* stream);
  * out [M, K_pad] bytes, columns K..K_pad zero; K_pad a multiple of 16. */
 int tribe_quantize_fp8_fwd(const void* x, int32_t x_dtype, int64_t M, int64_t K, int64_t ld, float inv_scale, uint8_t* out,
                            int64_t K_pad, void* stream);
+/* The pre-norm of an extractor layer fused with the quantisation of the Linear input that follows it (transformers' LlamaRMSNorm /
+ * nn.LayerNorm inside modeling_llama.py / modeling_vjepa2.py, then the e4m3 operand): y8 = tribe_quantize_fp8_fwd(bf16 output of
+ * tribe_rmsnorm_fwd (layernorm = 0, b NULL) or tribe_layernorm_fwd (layernorm = 1, b may be NULL)), bit for bit, in ONE pass over x
+ * (f32 [rows, dim], dim % 16 == 0; y8 [rows, dim] bytes). */
+int tribe_norm_quantize_fp8_fwd(const float* x, int64_t rows, int64_t dim, const float* w, const float* b, int32_t layernorm, float eps,
+                                float inv_scale, uint8_t* y8, void* stream);
 /* out[0] = max(out[0] if accumulate else 0, max |x|)  (device float; calibration of the per-tensor scales) */
 int tribe_absmax_fwd(const void* x, int32_t x_dtype, int64_t M, int64_t K, int64_t ld, float* out, int32_t accumulate, void* stream);
 

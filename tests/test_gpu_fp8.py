@@ -69,3 +69,23 @@ def test_gemm_fp8_swiglu_epilogue_and_errors():
     with pytest.raises(TypeError):
         ops.gemm_fp8_nt(qa.float(), qb, 1.0)
     assert _lib.lib().tribe_gemm_fp8(None, None) < 0
+
+
+@pytest.mark.parametrize("layernorm", [False, True])
+def test_norm_quantize_fused_is_bit_identical_to_two_passes(layernorm):
+    """tribe_norm_quantize_fp8_fwd == tribe_quantize_fp8_fwd(bf16 norm): same bytes, including saturated and sub-normal values."""
+    from tribe_hip import ops
+
+    g = torch.Generator().manual_seed(5)
+    rows, dim = 1027, 3072
+    x = (torch.randn(rows, dim, generator=g) * torch.logspace(-3, 2, rows).unsqueeze(1)).cuda()
+    x[5, 7] = 1e4                                                # one outlier row: the rest of it quantises to (near) zero
+    w = (1.0 + 0.2 * torch.randn(dim, generator=g)).cuda()
+    b = (0.1 * torch.randn(dim, generator=g)).cuda() if layernorm else None
+    for scale in (0.004, 0.02):                                  # the first one saturates the tail
+        two = ops.quantize_fp8(ops.layernorm(x, w, b, 1e-6) if layernorm else ops.rmsnorm(x, w, 1e-5), scale, K_pad=dim)
+        one = ops.norm_quantize_fp8(x, w, b, 1e-6 if layernorm else 1e-5, scale, layernorm)
+        assert one.shape == two.shape == (rows, dim)
+        assert torch.equal(one, two)
+    with pytest.raises(Exception):
+        ops.norm_quantize_fp8(x[:, :3064], w[:3064], None, 1e-5, 0.02, False)     # dim % 16
