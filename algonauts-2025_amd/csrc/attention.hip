@@ -159,6 +159,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
+  // Small heads are bound by the softmax's vector instructions, not by the matrix pipe: there the row sums of P come
+  // from one more MFMA per sub-tile -- A = all-ones, so every accumulator row holds sum_key P^T[key][q] of the SAME bf16 P the
+  // numerator uses -- instead of 8 adds per sub-tile and lane, and the final cross-lane reduction disappears as well.
+  constexpr bool LSUM_MFMA = C::NSUB > 1;
+  f32x4_t lacc = {0.f, 0.f, 0.f, 0.f};
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
   int kv_end = T;  // keys this workgroup can see
   if (CAUSAL) { const int last_q = qb * 128 + 127; kv_end = (last_q + 1 < T) ? last_q + 1 : T; }
@@ -246,6 +254,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       l_run *= alpha;
+      if (LSUM_MFMA) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lacc[r] *= alpha;
+      }
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float p = __builtin_amdgcn_exp2f(fmaf(sv[u][j], scale_log2e, -m_run));
-        psum += p;
+        if (!LSUM_MFMA) psum += p;
         pf[u][j] = (short)f32_to_bf16(p);
       }
     l_run += psum;
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     for (int u = 0; u < C::NSUB; ++u) {
       const int sub_key0 = t * C::KV + u * 32;
       if (sub_key0 >= T || (CAUSAL && sub_key0 > q0 + 15)) continue;  // P is all zero there
+      if (LSUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[u], lacc, 0, 0, 0);
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt) {
         // d-tile dt covers columns 16 dt .. +15 = chunks 2 dt, 2 dt + 1
@@ -296,8 +309,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
   }
 
   // ---- normalise and write: O^T[d = 16 dt + 4 fq + r][q = l15] -> out[q][h*DH + d], 4 consecutive d (8 bytes) per store ----
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
+  float l_tot;
+  if (LSUM_MFMA) {
+    l_tot = lacc[0];
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+  }
   const float inv = 1.0f / l_tot;
   const int q = q0 + l15;
   if (q < T) {
