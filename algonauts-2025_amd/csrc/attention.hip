@@ -28,6 +28,14 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
+// max(a, b, c) in one instruction.  fmaxf() chains compile to v_max_f32 PLUS a canonicalising v_max_f32 x, x per MFMA-produced input
+// (IEEE maxnum semantics): 56 instructions per 128-key tile at DH = 64 where 16 suffice.  Not volatile: the scheduler may move it.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 // keys per staged tile = 32 * NSUB: small heads take several 32-key sub-tiles per barrier / softmax pass so that the
 // fixed per-tile cost (barrier, max exchange, rescale test) is amortised over the same number of MFMAs as at DH = 384
 template <int DH>
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
         for (int r = 0; r < 4; ++r) { sv[u][r] = s0[r]; sv[u][4 + r] = s1[r]; }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pmax = fmaxf(pmax, fmaxf(sv[u][r], sv[u][4 + r]));
+      for (int r = 0; r < 4; ++r) pmax = max3f(pmax, sv[u][r], sv[u][4 + r]);
     }
     // the other three 16-lane groups hold the other keys of this query
     pmax = fmaxf(pmax, __shfl_xor(pmax, 16, 64));
