@@ -44,10 +44,48 @@ def _check_kwargs(target: type, kwargs: dict[str, tp.Any], implied: tuple[str, .
         raise ValueError(f"{target.__name__} needs {missing}")
 
 
-class BaseOptimizerConfig(pydantic.BaseModel):
+class _NamedConfig(pydantic.BaseModel):
+    """`{name: ...}` with unknown keys rejected -- the shape of every config block in this family."""
+
     model_config = pydantic.ConfigDict(extra="forbid")
     name: str
 
+    @classmethod
+    def _catalogue(cls) -> dict[str, type]:
+        return {}
+
+    @pydantic.field_validator("name")
+    @classmethod
+    def _name_is_known(cls, v: str) -> str:
+        known = cls._catalogue()
+        if known and v not in known:
+            raise ValueError(f"unknown name {v!r} for {cls.__name__}")
+        return v
+
+
+class BaseLRSchedulerConfig(_NamedConfig):
+    def build(self, optimizer: optim.Optimizer) -> optim.lr_scheduler.LRScheduler:
+        raise NotImplementedError
+
+
+class TorchLRSchedulerConfig(BaseLRSchedulerConfig):
+    """`{name, kwargs}` (base.py:62-78); `build(optimizer, **build_kwargs)` lets the caller add `total_steps` (pl_module.py:141-143)."""
+
+    kwargs: dict[str, tp.Any] = {}
+
+    @classmethod
+    def _catalogue(cls) -> dict[str, type]:
+        return _known(optim.lr_scheduler.LRScheduler)
+
+    def model_post_init(self, _ctx: tp.Any) -> None:
+        _check_kwargs(self._catalogue()[self.name], self.kwargs, implied=("optimizer",))
+
+    def build(self, optimizer: optim.Optimizer, **build_kwargs: tp.Any) -> optim.lr_scheduler.LRScheduler:
+        merged = {**self.kwargs, **build_kwargs}
+        return self._catalogue()[self.name](optimizer, **merged)
+
+
+class BaseOptimizerConfig(_NamedConfig):
     def build(self, params: tp.Iterable[torch.Tensor]) -> optim.Optimizer:
         raise NotImplementedError
 
@@ -59,57 +97,30 @@ class TorchOptimizerConfig(BaseOptimizerConfig):
     kwargs: dict[str, tp.Any] = {}
     HIP_BACKED: tp.ClassVar[tuple[str, ...]] = ("Adam", "AdamW")
 
-    @pydantic.field_validator("name")
     @classmethod
-    def _is_torch_optimizer(cls, v: str) -> str:
-        if v not in _known(optim.Optimizer):
-            raise ValueError(f"unknown torch optimizer {v!r}")
-        return v
+    def _catalogue(cls) -> dict[str, type]:
+        return _known(optim.Optimizer)
 
     def model_post_init(self, _ctx: tp.Any) -> None:
         if "lr" in self.kwargs:
             raise ValueError("lr should be defined as a base parameter instead of within kwargs.")
-        _check_kwargs(_known(optim.Optimizer)[self.name], self.kwargs, implied=("params", "lr"))
+        _check_kwargs(self._catalogue()[self.name], self.kwargs, implied=("params", "lr"))
+
+    def _on_hip(self, params: list[torch.Tensor]) -> bool:
+        plain = set(self.kwargs) <= {"betas", "eps", "weight_decay"}
+        on_gpu = bool(params) and all(isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float32 for p in params)
+        return self.name in self.HIP_BACKED and plain and on_gpu
 
     def build(self, params: tp.Iterable[torch.Tensor]) -> optim.Optimizer:
         params = list(params)
-        hip_ok = set(self.kwargs) <= {"betas", "eps", "weight_decay"} and params and all(
-            isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float32 for p in params)
-        if self.name in self.HIP_BACKED and hip_ok:
-            from modeling_utils.optim import HipAdam
+        if not self._on_hip(params):
+            return self._catalogue()[self.name](params, lr=self.lr, **self.kwargs)
+        from modeling_utils.optim import HipAdam
 
-            extra = dict(self.kwargs)
-            if self.name == "AdamW":
-                extra.setdefault("weight_decay", 1e-2)     # torch.optim.AdamW's default
-            return HipAdam(params, lr=self.lr, decoupled_weight_decay=self.name == "AdamW", **extra)
-        return _known(optim.Optimizer)[self.name](params, lr=self.lr, **self.kwargs)
-
-
-class BaseLRSchedulerConfig(pydantic.BaseModel):
-    model_config = pydantic.ConfigDict(extra="forbid")
-    name: str
-
-    def build(self, optimizer: optim.Optimizer) -> optim.lr_scheduler.LRScheduler:
-        raise NotImplementedError
-
-
-class TorchLRSchedulerConfig(BaseLRSchedulerConfig):
-    """`{name, kwargs}` (base.py:62-78); `build(optimizer, **build_kwargs)` lets the caller add `total_steps` (pl_module.py:141-143)."""
-
-    kwargs: dict[str, tp.Any] = {}
-
-    @pydantic.field_validator("name")
-    @classmethod
-    def _is_torch_scheduler(cls, v: str) -> str:
-        if v not in _known(optim.lr_scheduler.LRScheduler):
-            raise ValueError(f"unknown torch lr scheduler {v!r}")
-        return v
-
-    def model_post_init(self, _ctx: tp.Any) -> None:
-        _check_kwargs(_known(optim.lr_scheduler.LRScheduler)[self.name], self.kwargs, implied=("optimizer",))
-
-    def build(self, optimizer: optim.Optimizer, **build_kwargs: tp.Any) -> optim.lr_scheduler.LRScheduler:
-        return _known(optim.lr_scheduler.LRScheduler)[self.name](optimizer, **(self.kwargs | build_kwargs))
+        extra = dict(self.kwargs)
+        if self.name == "AdamW":
+            extra.setdefault("weight_decay", 1e-2)     # torch.optim.AdamW's default
+        return HipAdam(params, lr=self.lr, decoupled_weight_decay=self.name == "AdamW", **extra)
 
 
 class LightningOptimizerConfig(pydantic.BaseModel):
@@ -122,7 +133,8 @@ class LightningOptimizerConfig(pydantic.BaseModel):
     interval: tp.Literal["step", "epoch"] = "step"
 
     def build(self, params: tp.Iterable[torch.Tensor], **scheduler_build_kwargs: tp.Any) -> dict[str, tp.Any]:
-        built: dict[str, tp.Any] = {"optimizer": self.optimizer.build(params)}
-        if self.scheduler is not None:
-            built["lr_scheduler"] = {"scheduler": self.scheduler.build(built["optimizer"], **scheduler_build_kwargs), "interval": self.interval}
-        return built
+        opt = self.optimizer.build(params)
+        if self.scheduler is None:
+            return {"optimizer": opt}
+        schedule = self.scheduler.build(opt, **scheduler_build_kwargs)
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": schedule, "interval": self.interval}}
