@@ -354,3 +354,76 @@ def test_fit_with_bucketed_gradients_equals_plain_fit():
         finals.append([p.detach().cpu() for p in bm.parameters()])
     for a, b in zip(*finals):
         assert _rel(b, a) < 1e-4
+
+
+def _ddp_batches(rank: int | None, world: int):
+    from data_utils.dataloader import SegmentData
+
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    V, Tout, S, B, T = 50, 10, 3, 4, 31
+    out = []
+    for i in range(2):
+        data = tribe_ref.synthetic_batch(B, T, fdims, S, seed=60 + i)
+        data["fmri"] = torch.randn(B, V, Tout, generator=torch.Generator().manual_seed(70 + i))
+        if rank is not None:                                     # rank r of G takes sequences r::G
+            data = {k: v[rank::world].contiguous() for k, v in data.items()}
+        out.append(SegmentData(data=data, segments=[None] * next(iter(data.values())).shape[0]))
+    return fdims, V, Tout, S, out
+
+
+def _ddp_fit(rank: int | None, world: int):
+    from algonauts2025.model import FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from algonauts2025.trainer import Trainer
+    from modeling_utils.losses import TorchLossConfig
+    from modeling_utils.optimizers import LightningOptimizerConfig
+
+    fdims, V, Tout, S, batches = _ddp_batches(rank, world)
+    torch.manual_seed(11)                                        # same initial weights on every rank
+    model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=2, heads=4).build(fdims, V, Tout)
+    optim = LightningOptimizerConfig(optimizer={"name": "SGD", "lr": 0.05})    # linear in the gradient: a clean equivalence check
+    bm = BrainModule(model, TorchLossConfig(name="MSELoss").build(), optim, {})
+    trainer = Trainer(max_epochs=1, bucket_bytes=4 << 20)
+    trainer.fit(bm, batches)
+    return trainer, {n: p.detach().float().cpu() for n, p in bm.named_parameters()}
+
+
+def _ddp_worker(rank: int, world: int, port: int, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)                                     # rehearsal: both ranks share the one GPU, gloo carries the exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        trainer, weights = _ddp_fit(rank, world)
+        q.put((rank, {k: v.numpy() for k, v in weights.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_fit_matches_single_process():
+    """One process per rank, sequences r::2, GradReducer averaging the bucketed gradients (gloo between two processes on this one GPU;
+    RCCL on a real node): after two steps every rank holds the weights of the single-process run on the whole batch."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    _, want = _ddp_fit(None, 1)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [0, 1]
+    for rank, got in results.items():
+        worst = max(_rel(torch.from_numpy(got[n]), want[n]) for n in want)
+        assert worst < 2e-4, (rank, worst)
