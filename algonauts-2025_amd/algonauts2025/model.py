@@ -15,7 +15,8 @@ Data flow of `forward` (every step a HIP launch through libtribe_hip.so, nothing
     --tribe_voxel_head_fwd (grouped-by-subject MFMA GEMM)--> f32 [B,V,T]  (model.py:117-118)
     --tribe_adaptive_avg_pool_fwd--> f32 [B,V,T']                          (model.py:119-120)
 fp32 master parameters live in torch; bf16 packed copies are cached per parameter version.
-Forward only (inference / evaluation) in this round: no autograd graph is recorded.
+In `.eval()` / no-grad mode this fused path runs and records no autograd graph; in `.train()` mode with grad enabled
+`forward` composes the same arithmetic from the autograd functions of modeling_utils/autograd.py (HIP forward AND backward).
 """
 
 from __future__ import annotations
@@ -143,7 +144,11 @@ class FmriEncoder(nn.Module):
         semb, sid = None, None
         if add_embeddings and hasattr(self, "subject_embed"):
             semb = f32c(self.subject_embed.weight)
-            sid = data["subject_id"].flatten().to(torch.int64).contiguous()
+            # the projector epilogue gathers subject_embed rows by this index with no bounds check on the device:
+            # validate 0 <= id < n_subjects here (nn.Embedding raises IndexError in the reference, model.py:171-172)
+            sid = self.predictor.check_subjects(data["subject_id"])
+            if self.predictor.average_subjects:
+                sid = data["subject_id"].flatten().to(torch.int64).contiguous()
         width = (self.hidden // n_mod) * n_mod if cat else self.hidden
         x = torch.empty(B * T, width, dtype=torch.float32, device=device)
         slot = self.hidden // n_mod

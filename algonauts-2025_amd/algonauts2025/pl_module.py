@@ -118,6 +118,11 @@ class BrainModule(nn.Module):
         params = [p for p in self.parameters() if p.requires_grad]
         build = getattr(self.optim_config, "build", None)
         if build is not None:
+            if total_steps is None:
+                # Lightning calls configure_optimizers() with no argument; the reference then sizes OneCycleLR with
+                # self.trainer.estimated_stepping_batches (pl_module.py:139-143)
+                trainer = getattr(self, "trainer", None)
+                total_steps = getattr(trainer, "estimated_stepping_batches", None)
             return build(params, total_steps=total_steps)
         from modeling_utils.optim import HipAdam
 

@@ -68,7 +68,10 @@ class SubjectLayers(nn.Module):
         # that was already validated does not synchronise again.
         seen = getattr(self, "_checked", None)
         if seen is None or seen[0]() is not subjects or seen[1] != subjects._version:
-            assert subjects.max() < n, "Subject index higher than number of subjects used to initialize the weights."
+            lo, hi = (int(v) for v in torch.aminmax(subjects))    # one device->host sync for both bounds
+            assert hi < n, "Subject index higher than number of subjects used to initialize the weights."
+            if lo < 0:   # the reference's index_select / nn.Embedding raise on a negative id; the kernels gather unchecked
+                raise IndexError(f"index out of range in self: subject id {lo} < 0")
             self._checked = (weakref.ref(subjects), subjects._version)
         subjects = subjects.flatten().to(torch.int64)
         if self.average_subjects:

@@ -24,22 +24,24 @@ class HipAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError(f"Invalid Adam hyper-parameters: lr={lr} betas={betas} eps={eps} weight_decay={weight_decay}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled_weight_decay=decoupled_weight_decay))
-        self._chunks: dict[int, tuple[tuple, torch.Tensor, torch.Tensor]] = {}
+        self._chunks: dict[tuple, tuple[torch.Tensor, torch.Tensor]] = {}
 
     def _work_list(self, gi: int, params: list[torch.Tensor]) -> tuple[torch.Tensor, torch.Tensor]:
-        sig = tuple(p.numel() for p in params)
-        hit = self._chunks.get(gi)
-        if hit is None or hit[0] != sig:
+        sig = (gi,) + tuple(p.numel() for p in params)
+        hit = self._chunks.get(sig)
+        if hit is None:
             chunk = int(lib().tribe_adam_chunk_elems())
             owner, start = [], []
-            for i, n in enumerate(sig):
+            for i, n in enumerate(sig[1:]):
                 s = np.arange(0, n, chunk, dtype=np.int64)
                 owner.append(np.full(len(s), i, dtype=np.int32))
                 start.append(s)
             dev = params[0].device
-            hit = (sig, torch.from_numpy(np.concatenate(owner)).to(dev), torch.from_numpy(np.concatenate(start)).to(dev))
-            self._chunks[gi] = hit
-        return hit[1], hit[2]
+            if len(self._chunks) >= 16:      # parameter subsets change with modality dropout; keep the cache bounded
+                self._chunks.pop(next(iter(self._chunks)))
+            hit = (torch.from_numpy(np.concatenate(owner)).to(dev), torch.from_numpy(np.concatenate(start)).to(dev))
+            self._chunks[sig] = hit
+        return hit
 
     @torch.no_grad()
     def step(self, closure: tp.Callable[[], torch.Tensor] | None = None) -> torch.Tensor | None:
@@ -48,12 +50,15 @@ class HipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
-            params = [p for p in group["params"] if p.grad is not None]
-            if not params:
-                continue
-            table = np.zeros(len(params), dtype=_lib.ADAM_TENSOR_DTYPE)
-            step = None
-            for i, p in enumerate(params):
+            # torch.optim.Adam keeps a step count PER PARAMETER: one that had grad None on earlier steps (a projector whose
+            # modality was dropped, model.py:133-141) starts its bias corrections at 1 when it first receives a gradient.
+            # The kernel takes one step count per launch, so parameters are launched per distinct count (one launch in
+            # the steady state, two or three while late starters exist).
+            by_step: dict[int, list[torch.Tensor]] = {}
+            keep_alive = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise _lib.TribeHipError("HipAdam: parameters must be contiguous f32 tensors on the GPU (no CPU fallback)")
                 if p.grad.is_sparse:
@@ -64,21 +69,23 @@ class HipAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                step = int(st["step"]) if step is None else step
-                if int(st["step"]) != step:
-                    raise RuntimeError("HipAdam: parameters of one group must share their step count")
-                g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
-                table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-                st["_grad_ref"] = g                      # keep a converted gradient alive until the launch has run
-            owner, start = self._work_list(gi, params)
-            table_t = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(params[0].device)
+                by_step.setdefault(int(st["step"]), []).append(p)
             b1, b2 = group["betas"]
-            check(lib().tribe_adam_step(table_t.data_ptr(), owner.data_ptr(), start.data_ptr(), owner.numel(), float(group["lr"]), float(b1), float(b2),
-                                        float(group["eps"]), float(group["weight_decay"]), step, int(group["decoupled_weight_decay"]),
-                                        torch.cuda.current_stream().cuda_stream), "tribe_adam_step")
-            # the kernel wrote through raw pointers: tell autograd (and this build's packed-weight caches, which key on
-            # `_version`) that the parameters changed
-            torch.autograd.graph.increment_version(params)
-            for p in params:
-                self.state[p].pop("_grad_ref", None)
+            for step, params in by_step.items():
+                table = np.zeros(len(params), dtype=_lib.ADAM_TENSOR_DTYPE)
+                for i, p in enumerate(params):
+                    st = self.state[p]
+                    g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
+                    keep_alive.append(g)                      # a converted gradient must outlive the launch
+                    table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                owner, start = self._work_list(gi, params)
+                table_t = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(params[0].device)
+                keep_alive.append(table_t)
+                check(lib().tribe_adam_step(table_t.data_ptr(), owner.data_ptr(), start.data_ptr(), owner.numel(), float(group["lr"]), float(b1),
+                                            float(b2), float(group["eps"]), float(group["weight_decay"]), step, int(group["decoupled_weight_decay"]),
+                                            torch.cuda.current_stream().cuda_stream), "tribe_adam_step")
+                # the kernel wrote through raw pointers: tell autograd (and this build's packed-weight caches, which key on
+                # `_version`) that the parameters changed
+                torch.autograd.graph.increment_version(params)
+            del keep_alive      # torch's caching allocator keeps freed blocks ordered on the launch stream
         return loss

@@ -251,3 +251,21 @@ def test_reference_dims_pearson_parity():
     print(f"reference-dims parity: rel L2 err {rel:.3e}, max |dr| {dmax:.3e}")
     assert rel < 2e-2
     assert dmax < PEARSON_TOL, f"per-voxel Pearson differs by {dmax:.2e} (> {PEARSON_TOL})"
+
+
+def test_out_of_range_subject_ids_raise_before_any_gather():
+    """The reference raises on a subject id outside [0, n_subjects): the assert of common.py:53-55 for ids that are too
+    high, IndexError from nn.Embedding / index_select for negative ones.  The kernels gather by that index unchecked, so the
+    host must refuse both BEFORE the first launch (with subject_embedding the projector epilogue is the first consumer)."""
+    from algonauts2025.model import FmriEncoderConfig
+    from data_utils.dataloader import SegmentData
+
+    fdims = {"text": (2, 12), "audio": (2, 8), "video": (2, 10)}
+    for subj_emb in (False, True):
+        m = FmriEncoderConfig(n_subjects=3, hidden=768, depth=1, heads=2, subject_embedding=subj_emb).build(fdims, 11, 6).eval().cuda()
+        data = tribe_ref.synthetic_batch(2, 6, fdims, 3, seed=0)
+        for bad, exc in (([[0], [3]], AssertionError), ([[-1], [1]], IndexError)):
+            d = {k: v.cuda() for k, v in data.items()}
+            d["subject_id"] = torch.tensor(bad).cuda()
+            with pytest.raises(exc):
+                m(SegmentData(data=d, segments=[None] * 2))

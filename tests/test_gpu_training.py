@@ -3,6 +3,9 @@ Every forward and backward op of the training path is a HIP kernel; torch.autogr
 Tolerance: bf16 GEMM operands (activations, weights AND incoming gradients are rounded to bf16 before each MFMA
 product, f32 accumulation) vs an fp32 CPU graph -> per-tensor relative L2 error of a few 1e-2 at most."""
 
+import queue
+import time
+
 import pytest
 import torch
 
@@ -213,6 +216,78 @@ def test_hip_adam_matches_torch_adam():
         HipAdam([cpu_param], lr=1e-3).step()                      # no CPU fallback
 
 
+def test_hip_adam_late_starting_parameter_keeps_its_own_step_count():
+    """torch.optim.Adam counts steps per parameter: one whose grad was None on earlier steps (a projector whose modality was
+    dropped under `zero_grad(set_to_none=True)`, model.py:133-141) starts its bias corrections at 1 when it first gets a gradient."""
+    from modeling_utils.optim import HipAdam
+
+    torch.manual_seed(1)
+    shapes = [(257, 33), (1000,), (40, 7)]
+    ref = [torch.randn(s).requires_grad_() for s in shapes]
+    mine = [p.detach().clone().cuda().requires_grad_() for p in ref]
+    opt_ref, opt = torch.optim.Adam(ref, lr=1e-2), HipAdam(mine, lr=1e-2)
+    present = [[0, 2], [0, 2], [0, 1, 2], [1], [0, 1, 2]]        # parameter 1 joins at step 3; 0 and 2 sit out step 4
+    for active in present:
+        opt_ref.zero_grad(set_to_none=True), opt.zero_grad(set_to_none=True)
+        for i in active:
+            g = torch.randn(shapes[i])
+            ref[i].grad, mine[i].grad = g.clone(), g.clone().cuda()
+        opt_ref.step(), opt.step()
+        for a, b in zip(ref, mine):
+            torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=2e-6, atol=2e-7)
+    assert [float(opt.state[p]["step"]) for p in mine] == [4.0, 3.0, 4.0]
+
+
+def test_fit_with_modality_dropout_runs_and_matches_torch_adam():
+    """Trainer.fit WITHOUT a GradReducer at modality_dropout = 0.5 (the reference trains with 0.3, defaults.py): projectors whose
+    modality is dropped get grad None under zero_grad(set_to_none=True) and re-join later.  HipAdam must follow torch.optim.Adam
+    through the same draws (same host RNG stream => same dropped modalities)."""
+    import numpy as np
+
+    from algonauts2025.model import FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from data_utils.dataloader import SegmentData
+    from modeling_utils.losses.base import TorchLossConfig
+    from modeling_utils.optim import HipAdam
+
+    fdims = {"text": (2, 24), "audio": (2, 16), "video": (2, 20)}
+    B, T, V, S = 4, 24, 30, 2
+
+    class _Opt:
+        def __init__(self, make):
+            self.make = make
+
+        def build(self, params, total_steps=None):
+            return self.make(params)
+
+    def run(make_opt):
+        from algonauts2025.trainer import Trainer
+
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=1, heads=2, modality_dropout=0.5).build(fdims, V, T)
+        g = torch.Generator().manual_seed(3)
+        data = {m: torch.randn(B, l, d, T, generator=g) for m, (l, d) in fdims.items()}
+        data["subject_id"] = (torch.arange(B) % S).view(B, 1)
+        data["fmri"] = torch.randn(B, V, T, generator=g)
+        batch = SegmentData(data=data, segments=[None] * B)
+        module = BrainModule(model, TorchLossConfig(name="MSELoss").build(), _Opt(make_opt), {}, max_epochs=1)
+        seen = []
+        for prm in model.projectors.parameters():
+            prm.register_hook(lambda grad, _s=seen: _s.append(1))
+        torch.manual_seed(11)                                     # the dropout draws of the steps
+        trainer = Trainer(max_epochs=1, reduce_gradients=False)
+        trainer.fit(module, [batch] * 8)
+        n_proj = len(list(model.projectors.parameters()))
+        assert 0 < len(seen) < 8 * n_proj, "the draw sequence never dropped a modality: the late-start case is not covered"
+        return {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+
+    got = run(lambda ps: HipAdam(ps, lr=1e-3))
+    want = run(lambda ps: torch.optim.Adam(ps, lr=1e-3))
+    for n in want:
+        assert _rel(got[n], want[n]) < 1e-4, n
+
+
 @pytest.mark.parametrize("Z,R,Cc,pad_c", [(3, 70, 130, 0), (2, 1024, 384, 0), (1, 33, 5, 0), (4, 64, 64, 64), (2, 257, 36, 12)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_transpose_bf16_vector_and_scalar_paths(Z, R, Cc, pad_c, dtype):
@@ -395,7 +470,9 @@ def _ddp_worker(rank: int, world: int, port: int, q):
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)                                     # rehearsal: both ranks share the one GPU, gloo carries the exchange
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         trainer, weights = _ddp_fit(rank, world)
         q.put((rank, {k: v.numpy() for k, v in weights.items()}))
@@ -419,10 +496,28 @@ def test_two_rank_data_parallel_fit_matches_single_process():
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        results = {}
+        deadline = time.monotonic() + 300
+        while len(results) < len(procs):
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"rank process exited with code {dead[0].exitcode}"
+            assert time.monotonic() < deadline, "two-rank fit timed out"
+            try:
+                rank, weights = q.get(timeout=1.0)
+                results[rank] = weights
+            except queue.Empty:
+                pass
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:                                                      # never leave an orphan holding the GPU inside a gloo collective
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
     assert sorted(results) == [0, 1]
     for rank, got in results.items():
         worst = max(_rel(torch.from_numpy(got[n]), want[n]) for n in want)
