@@ -23,6 +23,8 @@
 // Roofline: MFMA (4*T*DH flop per query row and head); every MFMA streams a 1 KiB operand from LDS, so
 // the LDS read rate (256 B/clk/CU) is the co-bound.
 #include "gemm_common.h"
+#include "attn_acc_regs.h"
+#include <utility>
 
 namespace {
 
@@ -35,6 +37,21 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+
+// One LDS-DMA wave-instruction: lane l copies the 16 bytes at gsrc (per lane) to LDS byte address lds_dst + 16 l (lds_dst
+// wave-uniform).  Inline asm, NOT __builtin_amdgcn_global_load_lds: hipcc tracks the builtin as a VMEM write to LDS and, unable
+// to prove that a later ds_read touches another ring slot, puts s_waitcnt vmcnt(0) in front of the first LDS read after it --
+// every tile then drained ALL its LDS-DMA loads, the multi-slot rings of these kernels never had a tile in flight and each
+// tile paid a full L2 / HBM round trip (seen in the ISA of the round-1 kernels, and in stamps as 5900 of 7600 cycles per tile
+// when pieces were issued between MFMAs).  Unseen by the compiler, the loads are waited for by the kernels' own counted
+// s_waitcnt vmcnt(N) + barrier; hipcc's counted waits for its OWN loads stay correct (hidden younger loads only make a counted
+// wait cover more).  M0 is compiler-reserved: saved and restored inside the statement (guide 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lptr_t)p; }
 
 // keys per staged tile = 32 * NSUB: small heads take several 32-key sub-tiles per barrier / softmax pass so that the
 // fixed per-tile cost (barrier, max exchange, rescale test) is amortised over the same number of MFMAs as at DH = 384
@@ -138,8 +155,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
           const int row = (key0 + st_row[i] < T) ? st_row[i] : T - 1 - key0;
           off = row * (int)ld + st_src[i];
         }
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), (lptr_t)(kdst + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), (lptr_t)(kdst + C::TILE_BYTES + piece * 1024), 16, 0, 0);
+        glds16(kb + off, lds_addr(kdst + piece * 1024));
+        glds16(vb + off, lds_addr(kdst + C::TILE_BYTES + piece * 1024));
       }
     }
   };
@@ -338,6 +355,341 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// =====================================================================================================================
+// DH = 384, bidirectional (the TRIBE encoder, 10 % of the step): ONE wave per SIMD, 32 query rows per wave.
+//
+// The 16-row kernel above reads every K / V fragment (1 KiB) from LDS for ONE 16x16x32 MFMA: LDS bytes per flop are at the
+// array's limit and, at 242 VGPRs, the compiler keeps one or two fragments in flight, so every MFMA waits out most of an LDS
+// round trip (24 % of the MFMA peak, profiles/r01_n_*).  Here a wave owns 32 query rows and v_mfma_f32_32x32x16_bf16: every
+// fragment feeds twice the flops, and the wave has the whole 512-register file:
+//   * O^T [384 x 32 queries] = 12 accumulator tiles of 32x32 = 192 registers, pinned to AGPRs by the "+a" operands of the
+//     inline-asm MFMAs (the compiler would otherwise let them compete with Q for the 256 architectural VGPRs and spill);
+//   * Q^T fragments for all 24 k-steps in 96 VGPRs; S^T (16) / P^T (8) / the fragment pipeline (DEPTH x 4) in the rest;
+//   * the K / V fragment reads are software-pipelined DEPTH deep in SOURCE order, pinned with sched_barrier; the compiler
+//     still counts them (plain loads), so every MFMA waits with the exact lgkmcnt;
+//   * S^T = K Q^T puts the query on the lane (col = lane & 31): softmax state is one scalar per lane, the other 16 keys of a
+//     query sit in lane ^ 32 (v_permlane32_swap); the S^T accumulator IS the B operand of O^T += V^T P^T (guide section 3:
+//     element j of lane half h of k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3)), V^T read with ds_read_b64_tr_b16 in
+//     exactly that key order.
+// LDS image: plain 768-byte rows, 16-byte chunks swizzled inside each 256-byte segment by
+// chunk ^= ((row & 3) << 2) | ((row >> 2) & 3) (guide T10 image (b)): conflict-free for the 32-row ds_read_b128 of K (16 lanes
+// of a read group see 16 distinct row & 15) and for the transposed reads of V (a 32-lane half reads 4 keys x 64 bytes, the
+// keys' row & 3 spread them over four chunk quads).  K / V tiles of 32 keys arrive by LDS-DMA (inline asm, see stage_piece)
+// into a 2-slot K ring and a 4-slot V ring, six 1-KiB pieces per wave and PHASE: the L1 -> LDS path moves ~37 B/clk/CU when
+// bursts queue up (12 pieces in a row held the wave's issue for 1300 cycles, as long as the tile's 48 MFMAs).
+// One barrier per tile, between softmax and the P V product: at that point K and V of tile t + 1 have landed (issued a phase
+// and a tile earlier), so the first K fragments of tile t + 1 are prefetched under the last P V MFMAs of tile t, the first V
+// fragments under the last S^T MFMAs, and the matrix pipe does not drain at the seams.
+// Diagnostic build only (-DTRIBE_ATTN_STAMPS, scripts/attn_stamps.py): s_memtime stamps at the phase boundaries of the key loop,
+// summed per wave into a side buffer whose pointer rides in desc.rel_qe.  Never quote the run time of that build; read the shares.
+#ifdef TRIBE_ATTN_STAMPS
+#define ATTN_STAMP(var)                                                                   \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#define ATTN_STAMP_ADD(i, a, b) stamp_acc[i] += (b) - (a)
+#else
+#define ATTN_STAMP(var) do {} while (0)
+#define ATTN_STAMP_ADD(i, a, b) do {} while (0)
+#endif
+
+struct WideCfg {
+  static constexpr int DH = 384, KS = 24, DT = 12, ROWB = 768, KV = 32, CHUNKS = 48;
+  static constexpr int TILE_BYTES = KV * ROWB;       // 24 KiB per K or V tile
+  static constexpr int WAVES = 4, PPW = 6;           // 24 LDS-DMA pieces of 1 KiB per K or V tile, 6 per wave
+  static constexpr int K_SLOTS = 2, V_SLOTS = 4;     // see the ring schedule in the kernel
+  static constexpr int V_BASE = K_SLOTS * TILE_BYTES;
+  static constexpr int SMEM = (K_SLOTS + V_SLOTS) * TILE_BYTES;   // 144 KiB
+  static constexpr int DEPTH = 6;                    // fragments in flight per wave
+};
+
+__device__ __forceinline__ int swz_wide(int chunk, int row) {
+  return (chunk & ~15) | ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) & 15);
+}
+
+// compile-time loop: the accumulator tile index selects literal registers (attn_acc_regs.h)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// S^T accumulation in VGPRs (asm, so that the compiler never allocates an accumulator register of its own: a0..a191 belong to
+// O^T).  hipcc does not know these are MFMAs: the caller pads the result -> VALU hazard (s_nop after the last one).
+__device__ __forceinline__ void mfma_s_first(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_s(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// The value lane ^ 32 holds, combined with this lane's.  v_permlane32_swap exchanges lanes 32..63 of its first operand with
+// lanes 0..31 of its second: fed two COPIES of x it leaves x[lane & 31] in one register and x[32 + (lane & 31)] in the other, in
+// every lane.  Inline asm with two read-write operands: the builtin handed both copies the same register (the swap then only
+// rotates x by 32 lanes and a lane never sees its own value).  The s_nop pads the VALU-write -> permlane-read hazard.
+__device__ __forceinline__ void pair_split(float x, float& lo, float& hi) {
+  lo = x;
+  hi = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ float pair_max(float x) {
+  float lo, hi;
+  pair_split(x, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float pair_sum(float x) {
+  float lo, hi;
+  pair_split(x, lo, hi);
+  return lo + hi;
+}
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_wide384_kernel(const AttnArgs a) {
+  using C = WideCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+
+  const int T = a.T;
+  const float scale_log2e = a.scale_log2e;
+  // same XCD-aware walk as the 16-row kernel: all query blocks of one (sequence, head) pair run on one XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int qb = slot % a.qblocks;
+  const int pair = (slot / a.qblocks) * 8 + xcd;
+  if (pair >= a.n_bh) return;
+  const int hd = pair % a.heads_q;
+  const int b = pair / a.heads_q;
+  const int hk = hd / a.group;
+  const int64_t ld = a.ld_kv;
+  const unsigned short* qbase = a.q + (int64_t)b * T * a.ld_q + (int64_t)hd * C::DH;
+  const unsigned short* kbase = a.k + (int64_t)b * T * ld + (int64_t)hk * C::DH;
+  const unsigned short* vbase = a.v + (int64_t)b * T * ld + (int64_t)hk * C::DH;
+
+  // ---- Q^T fragments (B operand of S^T): lane (query r31, half h) holds Q[q][16 ks + 8 h .. +7] ----
+  const int q0 = qb * 128 + wave * 32;
+  const int qrow = (q0 + r31 < T) ? q0 + r31 : T - 1;
+  bf16x8_t qf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) qf[ks] = *(const bf16x8_t*)(qbase + (int64_t)qrow * a.ld_q + ks * 16 + h * 8);
+
+  // ---- staging plan: piece i of this wave covers linear 16-byte chunks [(wave + 4 i) * 64, +64) of a tile ----
+  int st_row[C::PPW], st_src[C::PPW], st_off[C::PPW];
+#pragma unroll
+  for (int i = 0; i < C::PPW; ++i) {
+    const int p = (wave + C::WAVES * i) * 64 + lane;
+    st_row[i] = p / C::CHUNKS;
+    st_src[i] = swz_wide(p % C::CHUNKS, st_row[i]) * 8;   // element offset of the SOURCE chunk inside the row
+    st_off[i] = st_row[i] * (int)ld + st_src[i];
+  }
+  // One 1-KiB piece of the K (which = 0) or V (which = 1) tile that starts at key0, into ring slot `slot` of that operand
+  auto stage_piece = [&](int which, int slot, int key0, int i) {
+    const unsigned short* src = (which ? vbase : kbase) + (int64_t)key0 * ld;
+    const int piece = wave + C::WAVES * i;
+    // tail keys (key0 + row >= T) re-read the last valid row; they are masked to -inf in the softmax
+    const int row = (key0 + st_row[i] < T) ? st_row[i] : T - 1 - key0;
+    const int off = (key0 + C::KV <= T) ? st_off[i] : row * (int)ld + st_src[i];
+    glds16(src + off, lds_addr(smem) + (which ? C::V_BASE : 0) + slot * C::TILE_BYTES + piece * 1024);
+  };
+  auto stage = [&](int which, int slot, int key0) {
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) stage_piece(which, slot, key0, i);
+  };
+
+  // ---- per-lane LDS byte offsets inside a slot: 8 for the K row reads, 8 for the V transposed reads; everything else is an
+  // immediate (segment, k-step half) or the slot base added once per tile ----
+  int kb_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) kb_off[i] = r31 * C::ROWB + swz_wide(2 * i + h, r31) * 16;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
+  int vb_off[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int lh = 0; lh < 2; ++lh) {
+      const int row = 4 * h + tq + 8 * lh;
+      vb_off[i][lh] = C::V_BASE + row * C::ROWB + swz_wide(4 * i + 2 * g1 + (tp >> 1), row) * 16 + (tp & 1) * 8;
+    }
+  auto ld_k = [&](const int (&ka)[8], int ks) -> bf16x8_t {
+    return *(const bf16x8_t*)(smem + ka[ks & 7] + (ks >> 3) * 256);
+  };
+  auto ld_v = [&](const int (&va)[4][2], int i) -> bf16x8_t {   // fragment i = 12 s + dt
+    const int s = i / C::DT, dt = i % C::DT;
+    const int imm = (dt >> 2) * 256 + s * 16 * C::ROWB;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[dt & 3][0] + imm));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[dt & 3][1] + imm));
+    bf16x8_t vf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+    return vf;
+  };
+
+  static_for<0, C::DT>([&](auto dt) { AccTile<decltype(dt)::value>::zero(); });   // O^T = 0 in a[0:191]
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (T + C::KV - 1) / C::KV;
+  // Ring schedule (6 LDS-DMA loads per wave and PHASE, so the L1 -> LDS path sees an even 32 B/clk instead of bursts):
+  //   S^T phase of tile t issues V(t + 2) into V slot (t + 2) % 4  (V(t - 2) was consumed before barrier t - 1);
+  //   P V phase of tile t issues K(t + 2) into K slot t % 2        (K(t) was consumed before barrier t);
+  //   the wait before barrier t leaves the 6 youngest loads (V(t + 2)) in flight: K(t + 1) and V(t + 1), issued a phase and a
+  //   tile earlier, have landed and become visible to every wave -- K(t + 1) for the prefetch under the last P V MFMAs of tile
+  //   t, V(t + 1) for the prefetch under the last S^T MFMAs of tile t + 1.
+  stage(0, 0, 0); stage(1, 0, 0);
+  if (ntiles > 1) { stage(0, 1, C::KV); stage(1, 1, C::KV); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+  else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8_t kf[C::KS], vf[2 * C::DT];
+  // The 16 read addresses live in registers for the whole kernel and are STEPPED from slot to slot by a scalar (opaque asm: the
+  // compiler otherwise precomputes one copy per slot, 48 registers, and spills the Q fragments to make room).
+  int ka[8], va[4][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ka[i] = kb_off[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { va[i][0] = vb_off[i][0]; va[i][1] = vb_off[i][1]; }
+#pragma unroll
+  for (int d = 0; d < C::DEPTH; ++d) kf[d] = ld_k(ka, d);
+
+#ifdef TRIBE_ATTN_STAMPS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+  unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0};   // 0 S^T phase, 1 softmax, 2 vmcnt wait, 3 barrier, 4 P V phase
+#endif
+  int vcur = 0;            // V slot of tile t
+  for (int t = 0; t < ntiles; ++t) {
+    ATTN_STAMP(ts0);
+    const bool more = t + 2 < ntiles;
+    const int vnext2 = (vcur + 2) & 3;
+
+    // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]: 24 k-steps of 16, K fragments DEPTH ahead, then the first V fragments ----
+    f32x16_t s;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + C::DEPTH < C::KS) kf[ks + C::DEPTH] = ld_k(ka, ks + C::DEPTH);
+      else vf[ks + C::DEPTH - C::KS] = ld_v(va, ks + C::DEPTH - C::KS);
+      if (ks % 4 == 1) { if (more) stage_piece(1, vnext2, (t + 2) * C::KV, ks / 4); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0) mfma_s_first(s, kf[ks], qf[ks]);
+      else mfma_s(s, kf[ks], qf[ks]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 11" : "+v"(s));   // 8-pass MFMA result -> first VALU read (hipcc pads its own MFMAs with 12 states here)
+    ATTN_STAMP(ts1);
+
+    // ---- online softmax: s[r] = S^T[key = 32 t + (r & 3) + 8 (r >> 2) + 4 h][q = r31], raw scores ----
+    if ((t + 1) * C::KV > T) {   // wave-uniform: the last tile of a sequence whose length is not a multiple of 32
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (t * C::KV + (r & 3) + 8 * (r >> 2) + 4 * h >= T) s[r] = -INFINITY;
+    }
+    float pmax = max3f(s[0], s[1], s[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) pmax = max3f(pmax, s[r], s[r + 1]);
+    pmax = fmaxf(pmax, s[15]);
+    pmax = pair_max(pmax) * scale_log2e;
+    if (!__all(pmax - m_run <= 8.0f)) {   // deferred max (guide T13): all P V products of earlier tiles are complete here
+      const float m_new = fmaxf(m_run, pmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+      if (t > 0) {   // at t = 0 O^T is still zero
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last P V MFMA -> v_accvgpr_read (24 S^T MFMAs ran in between; belt and braces)
+        static_for<0, C::DT>([&](auto dt) { AccTile<decltype(dt)::value>::scale(alpha); });
+        asm volatile("s_nop 7" ::: "memory");               // v_accvgpr_write -> MFMA C operand
+      }
+    }
+    bf16x8_t pf[2];
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));
+      psum += p;
+      pf[r >> 3][r & 7] = (short)f32_to_bf16(p);
+    }
+    l_run += psum;
+
+    // ---- K(t + 1) and V(t + 1) have landed for everyone after this barrier; every wave is done with K(t) and V(t - 1) ----
+    ATTN_STAMP(ts2);
+    if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // the 6 youngest = this wave's V(t + 2) pieces, just issued
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(ts3);
+    __builtin_amdgcn_s_barrier();
+    ATTN_STAMP(ts4);
+    // K read addresses flip to the other K slot (tile t + 1)
+    const int kslot = t & 1;
+    const int kstep = kslot ? -C::TILE_BYTES : C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(ka[i]) : "s"(kstep));
+    asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));   // VALU-written P fragments -> MFMA operands inside asm
+
+    // ---- O^T[d][q] += sum_key V[key][d] P^T[key][q]: 2 key halves x 12 d-tiles; the first K fragments of tile t + 1 ride
+    // under the last MFMAs (harmless stale reads after the last tile) ----
+    static_for<0, 2 * C::DT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + C::DEPTH < 2 * C::DT) vf[i + C::DEPTH] = ld_v(va, i + C::DEPTH);
+      else kf[i + C::DEPTH - 2 * C::DT] = ld_k(ka, i + C::DEPTH - 2 * C::DT);
+      if constexpr (i % 4 == 1) { if (more) stage_piece(0, kslot, (t + 2) * C::KV, i / 4); }
+      __builtin_amdgcn_sched_barrier(0);
+      AccTile<i % C::DT>::mfma(vf[i], pf[i / C::DT]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // V read addresses move on to the next of the four V slots
+    const int vstep = (vcur == 3) ? -3 * C::TILE_BYTES : C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("v_add_u32 %0, %1, %0" : "+v"(va[i][0]) : "s"(vstep));
+      asm volatile("v_add_u32 %0, %1, %0" : "+v"(va[i][1]) : "s"(vstep));
+    }
+    vcur = (vcur + 1) & 3;
+    ATTN_STAMP(ts5);
+    ATTN_STAMP_ADD(0, ts0, ts1); ATTN_STAMP_ADD(1, ts1, ts2); ATTN_STAMP_ADD(2, ts2, ts3); ATTN_STAMP_ADD(3, ts3, ts4); ATTN_STAMP_ADD(4, ts4, ts5);
+  }
+#ifdef TRIBE_ATTN_STAMPS
+  if (a.qe != nullptr && lane == 0) {
+    unsigned long long* dbg = (unsigned long long*)a.qe + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int i = 0; i < 5; ++i) dbg[i] = stamp_acc[i];
+    dbg[5] = (unsigned long long)ntiles;
+  }
+#endif
+
+  // ---- normalise and write: O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h][q = r31] -> out[q][hd * DH + d] ----
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  const float inv = 1.0f / pair_sum(l_run);
+  const int q = q0 + r31;
+  unsigned short* orow = a.out + ((int64_t)b * T + (q < T ? q : T - 1)) * a.ld_out + (int64_t)hd * C::DH + 4 * h;
+  static_for<0, C::DT>([&](auto dtc) {
+    constexpr int dt = decltype(dtc)::value;
+    float ov[16];
+    AccTile<dt>::read(ov);
+    if (q < T) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16x4_t pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = f32_to_bf16(ov[4 * g + e] * inv);
+        *(u16x4_t*)(orow + 32 * dt + 8 * g) = pk;
+      }
+    }
+  });
+}
+
+int launch_attn_wide384(const AttnArgs& a, int64_t B, hipStream_t s) {
+  using C = WideCfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_wide384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr_done = true;
+  }
+  const int64_t nblocks = (B * a.heads_q + 7) / 8 * 8 * a.qblocks;
+  if (nblocks >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: grid too large"); return -1; }
+  if ((int64_t)a.T * a.ld_kv >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: sequence too long for 32-bit offsets"); return -1; }
+  hipLaunchKernelGGL(attn_fwd_wide384_kernel, dim3((unsigned)nblocks), dim3(256), C::SMEM, s, a);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int DH, int CAUSAL, int RELKEY>
 int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
   using C = AttnCfg<DH>;
@@ -354,12 +706,17 @@ int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
   return 0;
 }
 
+int g_attn_wide384 = 1;   // 0: run DH = 384 on the 16-row kernel (A/B measurements, tribe_attention_set_mode(2))
+
 template <int DH>
 int launch_attn_dh(const AttnArgs& a, int64_t B, int causal, hipStream_t s) {
+  if (DH == 384 && !causal && g_attn_wide384) return launch_attn_wide384(a, B, s);
   return causal ? launch_attn<DH, 1, 0>(a, B, s) : launch_attn<DH, 0, 0>(a, B, s);
 }
 
 }  // namespace
+
+void tribe_internal_attention_set_wide384(int on) { g_attn_wide384 = on; }
 
 // returns 1 if a fused kernel exists for this head size, else 0 (caller falls back to the 3-kernel path)
 int tribe_internal_attention_fused_supported(int dim_head) {
@@ -385,6 +742,9 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
   a.n_bh = (int)(d->B * d->heads_q);
   a.qe = d->rel_qe; a.ld_qe = d->ld_rel_qe; a.qe_stride_h = d->rel_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
   hipStream_t s = (hipStream_t)stream;
+#ifdef TRIBE_ATTN_STAMPS
+  if (d->rel_qe && d->dim_head == 384) return launch_attn_dh<384>(a, d->B, d->causal, s);   // rel_qe carries the stamp buffer
+#endif
   if (d->rel_qe) {
     TRIBE_REQUIRE(d->dim_head == 64 && !d->causal, "tribe_attention_fwd_ex: the relative_key bias is built for dim_head 64, non-causal");
     TRIBE_REQUIRE(d->rel_left >= 0 && d->rel_right >= 0 && d->rel_stride_h >= d->rel_left + d->rel_right + 1 &&

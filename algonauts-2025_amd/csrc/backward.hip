@@ -208,10 +208,27 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* 
     ds[i] = (i < T) ? f32_to_bf16(bf16_to_f32(p[i]) * (dp[i] - delta) * scale) : (unsigned short)0;
 }
 
-__global__ void mse_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n, const float* __restrict__ gs,
-                               float* __restrict__ dp) {
+// dpred = gs * 2 (p - t) / n.  HBM-bound: 12 bytes per element; float4 streams, two pairs in flight per lane.
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                      const float* __restrict__ gs, float* __restrict__ dp, int vec) {
   const float k = gs[0] * 2.0f / (float)n;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dp[i] = k * (p[i] - t[i]);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = vec ? (n >> 2) : 0;
+  const float4* p4 = (const float4*)p;
+  const float4* t4 = (const float4*)t;
+  float4* d4 = (float4*)dp;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 a0 = load_nt_f4(p4 + i), b0 = load_nt_f4(t4 + i);
+    const float4 a1 = load_nt_f4(p4 + i + stride), b1 = load_nt_f4(t4 + i + stride);
+    d4[i] = make_float4(k * (a0.x - b0.x), k * (a0.y - b0.y), k * (a0.z - b0.z), k * (a0.w - b0.w));
+    d4[i + stride] = make_float4(k * (a1.x - b1.x), k * (a1.y - b1.y), k * (a1.z - b1.z), k * (a1.w - b1.w));
+  }
+  for (; i < n4; i += stride) {
+    const float4 a = p4[i], b = t4[i];
+    d4[i] = make_float4(k * (a.x - b.x), k * (a.y - b.y), k * (a.z - b.z), k * (a.w - b.w));
+  }
+  for (int64_t j = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) dp[j] = k * (p[j] - t[j]);
 }
 
 __global__ void pool_bwd_kernel(const float* __restrict__ dy, int64_t rows, int64_t T_in, int64_t T_out, float* __restrict__ dx) {
@@ -259,15 +276,16 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, int64_t n4, unsign
   }
 }
 
-// one workgroup per voxel: d(1 - r)/dx_i = -( yc_i / den - cov * sy * xc_i / (sx * den^2) ),  den = sx * sy + 1e-8
+// d(1 - r)/dx_i = -( yc_i / den - cov * sy * xc_i / (sx * den^2) ),  den = sx * sy + 1e-8.  Workgroup (v, chunk): voxel v of a run
+// of sequences, one row per wave at a time (HBM-bound, 12 bytes per element; float4 when the rows allow it).
 __global__ __launch_bounds__(256) void pearson_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
                                                                int64_t B, int64_t V, int64_t T, int64_t sb, int64_t sv, int64_t st,
                                                                const double* __restrict__ stats, float w, const float* __restrict__ gs,
-                                                               float* __restrict__ dpred) {
+                                                               float* __restrict__ dpred, int64_t rows_per_wg, int vec) {
   const int64_t v = blockIdx.x;
   const double* s = stats + v * 6;
   const double n = s[5];
-  const double mx = s[0] / n, my = s[1] / n;
+  const float mx = (float)(s[0] / n), my = (float)(s[1] / n);
   const double cov = s[4] - s[0] * s[1] / n;
   double vx = s[2] - s[0] * s[0] / n, vy = s[3] - s[1] * s[1] / n;
   vx = vx > 0.0 ? vx : 0.0;
@@ -277,11 +295,24 @@ __global__ __launch_bounds__(256) void pearson_loss_bwd_kernel(const float* __re
   const float k = gs[0] * w;
   const float a = -k / den;                                               // * yc_i
   const float c = (sx > 0.f) ? k * (float)cov * sy / (sx * den * den) : 0.f;  // * xc_i
-  for (int64_t b = 0; b < B; ++b)
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-      const float xc = pred[b * sb + v * sv + t * st] - (float)mx, yc = truth[b * sb + v * sv + t * st] - (float)my;
-      dpred[(b * V + v) * T + t] = a * yc + c * xc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b0 = (int64_t)blockIdx.y * rows_per_wg;
+  const int64_t b1 = (b0 + rows_per_wg < B) ? b0 + rows_per_wg : B;
+  for (int64_t b = b0 + wave; b < b1; b += 4) {
+    const float* x = pred + b * sb + v * sv;
+    const float* y = truth + b * sb + v * sv;
+    float* d = dpred + (b * V + v) * T;
+    if (vec) {
+      const int64_t T4 = T >> 2;
+      for (int64_t i = lane; i < T4; i += 64) {
+        const float4 xa = load_nt_f4((const float4*)x + i), ya = load_nt_f4((const float4*)y + i);
+        ((float4*)d)[i] = make_float4(a * (ya.x - my) + c * (xa.x - mx), a * (ya.y - my) + c * (xa.y - mx),
+                                      a * (ya.z - my) + c * (xa.z - mx), a * (ya.w - my) + c * (xa.w - mx));
+      }
+    } else {
+      for (int64_t t = lane; t < T; t += 64) d[t] = a * (y[t * st] - my) + c * (x[t * st] - mx);
     }
+  }
 }
 
 __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ S, int64_t N, int64_t ld, float* __restrict__ lse,
@@ -471,7 +502,11 @@ extern "C" int tribe_softmax_fwd(const float* S, int64_t rows, int64_t T, int64_
 
 extern "C" int tribe_mse_bwd(const float* pred, const float* truth, int64_t n, const float* gscale, float* dpred, void* stream) {
   TRIBE_REQUIRE(pred && truth && gscale && dpred && n > 0, "tribe_mse_bwd: bad argument");
-  hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, truth, n, gscale, dpred);
+  const int vec = ((uintptr_t)pred % 16) == 0 && ((uintptr_t)truth % 16) == 0 && ((uintptr_t)dpred % 16) == 0;
+  int64_t nb = (n / 4 + 511) / 512;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pred, truth, n, gscale, dpred, vec);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }
@@ -494,8 +529,16 @@ extern "C" int tribe_pearson_loss_bwd(const float* pred, const float* truth, int
                                       int64_t st, const double* stats, int32_t reduction_sum, const float* gscale, float* dpred,
                                       void* stream) {
   TRIBE_REQUIRE(pred && truth && stats && gscale && dpred && B > 0 && V > 0 && T > 0, "tribe_pearson_loss_bwd: bad argument");
-  hipLaunchKernelGGL(pearson_loss_bwd_kernel, dim3((unsigned)V), dim3(256), 0, (hipStream_t)stream, pred, truth, B, V, T, sb, sv, st, stats,
-                     reduction_sum ? 1.0f : 1.0f / (float)V, gscale, dpred);
+  const int vec = st == 1 && T % 4 == 0 && sb % 4 == 0 && sv % 4 == 0 && ((uintptr_t)pred % 16) == 0 && ((uintptr_t)truth % 16) == 0 &&
+                  ((uintptr_t)dpred % 16) == 0;
+  int64_t chunks = (4096 + V - 1) / V;
+  if (chunks > (B + 3) / 4) chunks = (B + 3) / 4;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 65535) chunks = 65535;
+  const int64_t rows_per_wg = (B + chunks - 1) / chunks;
+  chunks = (B + rows_per_wg - 1) / rows_per_wg;
+  hipLaunchKernelGGL(pearson_loss_bwd_kernel, dim3((unsigned)V, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, pred, truth, B, V, T, sb, sv,
+                     st, stats, reduction_sum ? 1.0f : 1.0f / (float)V, gscale, dpred, rows_per_wg, vec);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

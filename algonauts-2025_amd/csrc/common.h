@@ -25,6 +25,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 }
 
 // ---- wave / block reductions ---------------------------------------------------
+// streaming (read-once) 16-byte load: keeps a one-pass reduction from evicting what L2 / MALL hold for the GEMMs
+typedef float tribe_f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_nt_f4(const void* p) {
+  const tribe_f32x4_nt v = __builtin_nontemporal_load((const tribe_f32x4_nt*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

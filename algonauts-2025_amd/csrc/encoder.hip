@@ -13,10 +13,12 @@ int tribe_internal_attention_fused_supported(int dim_head);
 int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
                                    hipStream_t s);
 
+void tribe_internal_attention_set_wide384(int on);
 static int g_attn_mode = 0;  // 0 = fused kernel when the head size has one, 1 = always the 3-kernel (materialised) path
 extern "C" int tribe_attention_set_mode(int32_t mode) {
-  TRIBE_REQUIRE(mode == 0 || mode == 1, "tribe_attention_set_mode: mode must be 0 (auto) or 1 (materialised scores)");
-  g_attn_mode = mode;
+  TRIBE_REQUIRE(mode >= 0 && mode <= 2, "tribe_attention_set_mode: mode must be 0 (auto), 1 (materialised scores) or 2 (fused, 16-row waves at every head size)");
+  tribe_internal_attention_set_wide384(mode != 2);
+  g_attn_mode = mode == 1 ? 1 : 0;
   return 0;
 }
 

@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256) void segment_gather_rows_kernel(const tribe_fe
 
 // ---- word features: out[row] = sum of the table rows listed for (segment, step) `row`, as bf16 ---------------------
 // CSR lists keep the reference's order (event order inside the segment), so the fp32 sum is the reference's sum.
-template <int VEC>
+template <int VEC, bool F32OUT>
 __global__ __launch_bounds__(256) void word_bag_kernel(const float* __restrict__ table, int64_t C, const int32_t* __restrict__ row_ptr,
-                                                       const int32_t* __restrict__ word_idx, unsigned short* __restrict__ out,
-                                                       int64_t C_pad) {
+                                                       const int32_t* __restrict__ word_idx, void* __restrict__ out_v, int64_t C_pad) {
   const int64_t row = blockIdx.x;
   const int w0 = row_ptr[row], w1 = row_ptr[row + 1];
-  unsigned short* dst = out + row * C_pad;
+  unsigned short* dst = (unsigned short*)out_v + row * C_pad;
+  float* dst32 = (float*)out_v + row * C_pad;
   for (int64_t q = threadIdx.x; q < C_pad / VEC; q += 256) {
     float acc[VEC];
 #pragma unroll
@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void word_bag_kernel(const float* __restrict__
         }
       }
     }
-    if (VEC == 4) {
+    if (F32OUT) {
+      if (VEC == 4) *(float4*)(dst32 + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      else dst32[q] = acc[0];
+    } else if (VEC == 4) {
       u16x4_t o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(acc[k]);
@@ -309,21 +312,35 @@ extern "C" int tribe_segment_gather_fwd(const tribe_feature_piece* pieces, const
   return 0;
 }
 
-extern "C" int tribe_word_bag_fwd(const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
-                                  int64_t rows, uint16_t* out, int64_t C_pad, void* stream) {
-  TRIBE_REQUIRE(table && row_ptr && word_idx && out, "tribe_word_bag_fwd: null pointer");
-  TRIBE_REQUIRE(n_words > 0 && C > 0 && rows > 0 && rows < 2147483647LL, "tribe_word_bag_fwd: bad shape words=%lld C=%lld rows=%lld",
+static int word_bag_launch(const char* who, const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
+                           int64_t rows, void* out, int64_t C_pad, bool f32out, void* stream) {
+  TRIBE_REQUIRE(table && row_ptr && word_idx && out, "%s: null pointer", who);
+  TRIBE_REQUIRE(n_words > 0 && C > 0 && rows > 0 && rows < 2147483647LL, "%s: bad shape words=%lld C=%lld rows=%lld", who,
                 (long long)n_words, (long long)C, (long long)rows);
-  TRIBE_REQUIRE(C_pad >= C && C_pad % 8 == 0, "tribe_word_bag_fwd: C_pad=%lld must be >= C=%lld and a multiple of 8", (long long)C_pad,
-                (long long)C);
+  TRIBE_REQUIRE(C_pad >= C && (f32out || C_pad % 8 == 0), "%s: C_pad=%lld must be >= C=%lld (and a multiple of 8 for bf16 rows)", who,
+                (long long)C_pad, (long long)C);
   hipStream_t s = (hipStream_t)stream;
-  const bool vec = C % 4 == 0 && ((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 8) == 0;
-  if (vec)
-    hipLaunchKernelGGL(word_bag_kernel<4>, dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, (unsigned short*)out, C_pad);
+  const bool vec = C % 4 == 0 && C_pad % 4 == 0 && ((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  if (vec && f32out)
+    hipLaunchKernelGGL((word_bag_kernel<4, true>), dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, out, C_pad);
+  else if (vec)
+    hipLaunchKernelGGL((word_bag_kernel<4, false>), dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, out, C_pad);
+  else if (f32out)
+    hipLaunchKernelGGL((word_bag_kernel<1, true>), dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, out, C_pad);
   else
-    hipLaunchKernelGGL(word_bag_kernel<1>, dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, (unsigned short*)out, C_pad);
+    hipLaunchKernelGGL((word_bag_kernel<1, false>), dim3((unsigned)rows), dim3(256), 0, s, table, C, row_ptr, word_idx, out, C_pad);
   TRIBE_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int tribe_word_bag_fwd(const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
+                                  int64_t rows, uint16_t* out, int64_t C_pad, void* stream) {
+  return word_bag_launch("tribe_word_bag_fwd", table, n_words, C, row_ptr, word_idx, rows, out, C_pad, false, stream);
+}
+
+extern "C" int tribe_word_bag_f32_fwd(const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
+                                      int64_t rows, float* out, void* stream) {
+  return word_bag_launch("tribe_word_bag_f32_fwd", table, n_words, C, row_ptr, word_idx, rows, out, C, true, stream);
 }
 
 extern "C" int tribe_transpose_f32_fwd(const float* in, int64_t Z, int64_t R, int64_t C, float* out, void* stream) {

@@ -107,3 +107,30 @@ def load_into_store(store: tp.Any, name: str, folder: str | Path, events_by_key:
         store.put(name, ev, np.asarray(arr))
         n += 1
     return n
+
+
+class FeatureCacheFile:
+    """Dict-like view of one cache folder (key -> array) for the feature plugins' `infra.folder`: `in`, `[]` (memory-mapped
+    read), `[] =` (append).  The index is read on first use and kept in step with this object's own writes."""
+
+    def __init__(self, folder: str | Path) -> None:
+        self.folder = Path(folder)
+        self._items: dict[str, np.ndarray] | None = None
+
+    def _index(self) -> dict[str, np.ndarray]:
+        if self._items is None:
+            self._items = dict(iter_cache(self.folder)) if self.folder.exists() else {}
+        return self._items
+
+    def __contains__(self, key: str) -> bool:
+        return str(key) in self._index()
+
+    def __getitem__(self, key: str) -> np.ndarray:
+        return self._index()[str(key)]
+
+    def __setitem__(self, key: str, arr: np.ndarray) -> None:
+        write_cache(self.folder, [(str(key), arr)])
+        self._items = None                      # re-map on next read: the data file grew
+
+    def __len__(self) -> int:
+        return len(self._index())

@@ -16,10 +16,14 @@ from __future__ import annotations
 import ctypes as C
 import typing as tp
 
+import numpy as np
+import pydantic
 import torch
 
 from tribe_hip import ops
 from tribe_hip._lib import ConformerLayer, W2vBertDesc, check, lib
+
+from .plugin import HbmFeaturePlugin
 
 # facebook/w2v-bert-2.0 hyper-parameters (public model card; configuration input, not verifiable offline)
 W2V_BERT_2 = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
@@ -108,3 +112,100 @@ class HipWav2Vec2Bert:
         check(lib().tribe_w2vbert_fwd(C.byref(d), states.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
               "tribe_w2vbert_fwd")
         return states.permute(1, 0, 3, 2).contiguous()  # [B, n_states, dim, n_out]
+
+
+class Wav2VecBert(HbmFeaturePlugin):
+    """The reference's audio feature (audio.py:27-263) on the HIP conformer forward: fields `name`, `layers`,
+    `layer_aggregation`, `device`, `infra`; `prepare`, `__call__ -> Tensor[L, D, T]`, `_get_data -> [25, 1024, T_event@2Hz]`
+    per Sound event (item uid `filepath_offset_duration`, audio.py:145-149).  Waveform IO (`event.read()`), resampling and the
+    HF filterbank front end stay on the host as in the reference (third-party there too); everything from `input_features`
+    on -- 24 conformer layers, all 25 hidden states, the nearest-neighbour resampling to 2 Hz -- is one C call."""
+
+    name: tp.Literal["Wav2VecBert"] = "Wav2VecBert"
+    pretrained: str = "facebook/w2v-bert-2.0"             # audio.py:47,222; resolved from the local HF cache only
+    _EVENT_TYPE: tp.ClassVar[str] = "Sound"
+    _KIND: tp.ClassVar[str] = "sampled"
+    _model: tp.Any = pydantic.PrivateAttr(default=None)
+    _feature_extractor: tp.Any = pydantic.PrivateAttr(default=None)
+
+    def attach(self, model: HipWav2Vec2Bert, feature_extractor: tp.Any = None) -> "Wav2VecBert":
+        """Provide weights (+ optionally the filterbank front end) explicitly (offline use)."""
+        self._model = model
+        if feature_extractor is not None:
+            self._feature_extractor = feature_extractor
+        return self
+
+    @property
+    def model(self) -> HipWav2Vec2Bert:
+        if self._model is None:
+            self._model = self._get_sound_model()
+        return self._model
+
+    def _get_sound_model(self) -> HipWav2Vec2Bert:
+        from transformers import Wav2Vec2BertModel
+
+        hf = Wav2Vec2BertModel.from_pretrained(self.pretrained, local_files_only=True)
+        return HipWav2Vec2Bert(hf.config, hf.state_dict())
+
+    @property
+    def feature_extractor(self) -> tp.Any:
+        if self._feature_extractor is None:
+            self._feature_extractor = self._get_feature_extractor()
+        return self._feature_extractor
+
+    def _get_feature_extractor(self) -> tp.Any:
+        from transformers import AutoFeatureExtractor, SeamlessM4TFeatureExtractor
+
+        try:
+            return AutoFeatureExtractor.from_pretrained(self.pretrained, local_files_only=True)
+        except Exception:
+            # the checkpoint's preprocessor_config is not cached: the class the model card names, at its defaults
+            # (80 mel bins, stride 2 -> 160-dim frames at 50 Hz, 16 kHz); parity with the hub file is unpinned offline
+            return SeamlessM4TFeatureExtractor()
+
+    @property
+    def _input_frequency(self) -> float:
+        return getattr(self.feature_extractor, "sampling_rate", 16_000)
+
+    def _item_uid(self, event: tp.Any) -> str:
+        return f"{event.filepath}_{event.offset:.2f}_{event.duration:.2f}"
+
+    def _preprocess_wav(self, wav: torch.Tensor) -> torch.Tensor:
+        wav = torch.mean(wav, dim=1)                                   # audio.py:123-127: mono, z-scored
+        return (wav - wav.mean()) / (1e-8 + wav.std())
+
+    def _resample_wav(self, wav: torch.Tensor, old_frequency: float, new_frequency: float) -> torch.Tensor:
+        """audio.py:129-138 uses julius.ResampleFrac (absent here): same role, scipy's polyphase resampler -- a different
+        anti-aliasing filter, so resampled waveforms are parity-unpinned; at equal rates the waveform passes through."""
+        old, new = int(old_frequency), int(new_frequency)
+        if old == new:
+            return wav
+        from scipy.signal import resample_poly
+
+        return torch.from_numpy(resample_poly(wav.numpy(), new, old, axis=0).astype("float32"))
+
+    def _get_features(self, wav: torch.Tensor) -> torch.Tensor:
+        out = self.feature_extractor(wav.numpy(), return_tensors="pt", sampling_rate=self.feature_extractor.sampling_rate, do_normalize=True)
+        try:
+            return out["input_features"]
+        except KeyError:
+            return out["input_values"]
+
+    def _process_wav(self, wav: torch.Tensor, timepoints: int) -> torch.Tensor:
+        """audio.py:253-263 + 163-171 in one launch sequence: f32 [n_states, dim, timepoints] on the GPU."""
+        return self.model.hidden_states_resampled(self._get_features(wav), timepoints)[0]
+
+    def _compute(self, events: list[tp.Any]) -> tp.Iterator[np.ndarray]:
+        from ..base import Frequency
+
+        for event in events:
+            got = event.read()
+            if hasattr(got, "audio"):                                   # a Video event: its sound track (audio.py:155-158)
+                audio = got.audio
+                wav, sfreq = torch.tensor(audio.to_soundarray(), dtype=torch.float32), audio.fps
+            else:
+                wav, sfreq = torch.as_tensor(got, dtype=torch.float32), event.frequency
+            if wav.ndim == 1:
+                wav = wav[:, None]
+            wav = self._preprocess_wav(self._resample_wav(wav, sfreq, self._input_frequency))
+            yield self._process_wav(wav, Frequency(2.0).to_ind(event.duration)).cpu().numpy()

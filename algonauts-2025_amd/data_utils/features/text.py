@@ -29,7 +29,7 @@ import torch
 from tribe_hip import _lib, ops
 from tribe_hip._lib import LlamaDesc, LlamaLayer, check, lib
 
-from .layers import aggregate_layers
+from .plugin import HbmFeaturePlugin
 
 # Llama-3.2-3B hyper-parameters (public model card; not verifiable offline -> configuration input)
 LLAMA_3P2_3B = dict(
@@ -190,48 +190,59 @@ def word_pool_windows(input_ids: torch.Tensor, target_words: tp.Sequence[str], p
     return (n_real - k).to(torch.int64), k.to(torch.int64)
 
 
-class LLAMA3p2(pydantic.BaseModel):
-    """Config surface of the reference feature (text.py:42-62); `prepare` / event plumbing (exca caches, TimedArray)
-    is out of scope -- `extract` is the hot path."""
+class LLAMA3p2(HbmFeaturePlugin):
+    """The reference's text feature (text.py:42-256) on the HIP Llama forward: fields `name`, `layers`, `layer_aggregation`,
+    `device`, `infra`; `prepare(events)`, `__call__(events, start, duration, trigger) -> Tensor[L, D, T]` and
+    `_get_data(events) -> Iterator[np.ndarray [n_states, hidden]]` (data_utils/features/plugin.py).  One latent per Word
+    event (item uid `text_context`, text.py:199-203), held for the word's duration."""
 
-    model_config = pydantic.ConfigDict(extra="forbid", arbitrary_types_allowed=True)
     name: tp.Literal["LLAMA3p2"] = "LLAMA3p2"
-    layers: list[float] = [0.5, 0.75, 1.0]
-    layer_aggregation: tp.Literal["group_mean"] | None = "group_mean"
-    device: tp.Literal["auto", "cpu", "cuda"] = "auto"
-    batch_size: int = 8  # text.py:212
-    pretrained: str = "meta-llama/Llama-3.2-3B"
+    batch_size: int = 8                                   # text.py:212 (DataLoader batch of contexts)
+    pretrained: str = "meta-llama/Llama-3.2-3B"           # text.py:166-173; resolved from the local HF cache only
+    _EVENT_TYPE: tp.ClassVar[str] = "Word"
+    _KIND: tp.ClassVar[str] = "words"
     _model: tp.Any = pydantic.PrivateAttr(default=None)
     _tokenizer: tp.Any = pydantic.PrivateAttr(default=None)
 
     def attach(self, model: HipLlamaModel, tokenizer: tp.Any) -> "LLAMA3p2":
-        """Provide weights + tokenizer explicitly (offline use)."""
+        """Provide weights + tokenizer explicitly (offline use: the reference fetches them by name)."""
         self._model, self._tokenizer = model, tokenizer
         return self
 
-    def _load(self) -> None:
-        if self._model is not None:
-            return
-        from transformers import AutoModel, AutoTokenizer  # local cache only: there is no network on the GPU boxes
+    @property
+    def model(self) -> HipLlamaModel:
+        if self._model is None:
+            from transformers import AutoModel, AutoTokenizer  # local cache only: there is no network on the GPU boxes
 
-        tok = AutoTokenizer.from_pretrained(self.pretrained, truncation_side="left", local_files_only=True)
-        hf = AutoModel.from_pretrained(self.pretrained, local_files_only=True)
-        if tok.pad_token is None:
-            tok.pad_token = tok.eos_token
-        self._model, self._tokenizer = HipLlamaModel(hf.config, hf.state_dict()), tok
+            tok = AutoTokenizer.from_pretrained(self.pretrained, truncation_side="left", local_files_only=True)
+            hf = AutoModel.from_pretrained(self.pretrained, local_files_only=True)
+            if tok.pad_token is None:
+                tok.pad_token = tok.eos_token
+            self._model, self._tokenizer = HipLlamaModel(hf.config, hf.state_dict()), tok
+        return self._model
+
+    @property
+    def tokenizer(self) -> tp.Any:
+        self.model
+        return self._tokenizer
+
+    def _item_uid(self, event: tp.Any) -> str:
+        return f"{event.text}_{event.context}"
+
+    def _compute(self, events: list[tp.Any]) -> tp.Iterator[np.ndarray]:
+        return self.extract([e.text for e in events], [e.context for e in events])
 
     def extract(self, target_words: tp.Sequence[str], contexts: tp.Sequence[str]) -> tp.Iterator[np.ndarray]:
-        """`_get_data` without the event / cache plumbing: yields [n_states, hidden] per word (text.py:204-256)."""
-        self._load()
-        tok = self._tokenizer
+        """The body of the reference's `_get_data` loop (text.py:204-256): yields [n_states, hidden] per word."""
+        model, tok = self.model, self.tokenizer
         pad_id = tok.eos_token_id
         for i in range(0, len(contexts), self.batch_size):
             words, ctx = list(target_words[i:i + self.batch_size]), list(contexts[i:i + self.batch_size])
             enc = tok(ctx, add_special_tokens=False, return_tensors="pt", padding=True, truncation=True)
             start, length = word_pool_windows(enc["input_ids"], words, pad_id)
-            states = self._model.forward_pooled(enc["input_ids"], start, length).cpu().numpy()  # [n_states, B, dim]
+            states = model.forward_pooled(enc["input_ids"], start, length).cpu().numpy()  # [n_states, B, dim]
             for j in range(len(words)):
                 yield states[:, j]
 
     def aggregate(self, latents: np.ndarray) -> np.ndarray:
-        return aggregate_layers(latents, self.layers, self.layer_aggregation)
+        return self._aggregate_layers(latents)

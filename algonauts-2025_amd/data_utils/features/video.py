@@ -14,10 +14,14 @@ from __future__ import annotations
 import ctypes as C
 import typing as tp
 
+import numpy as np
+import pydantic
 import torch
 
 from tribe_hip import ops
 from tribe_hip._lib import Vjepa2Desc, VitLayer, check, lib
+
+from .plugin import HbmFeaturePlugin
 
 # facebook/vjepa2-vitg-fpc64-256 hyper-parameters (public model card; configuration input, not verifiable offline)
 VJEPA2_VITG_FPC64_256 = dict(patch_size=16, crop_size=256, frames_per_clip=64, tubelet_size=2, hidden_size=1408, in_chans=3,
@@ -148,3 +152,77 @@ class HipVJEPA2Encoder:
         check(lib().tribe_vjepa2_fwd(C.byref(d), states.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
               "tribe_vjepa2_fwd")
         return states.transpose(0, 1).contiguous()
+
+
+def default_video_processor(frames: np.ndarray, crop_size: int = 256) -> torch.Tensor:
+    """What the HF `VJEPA2VideoProcessor` does at its defaults (video_processing_vjepa2.py: resize shortest edge to
+    int(crop * 256 / 224) bilinear, centre crop, rescale 1/255, ImageNet normalise) for uint8 frames [F, H, W, 3] ->
+    f32 [1, F, 3, crop, crop].  The HF class needs torchvision (absent); its interpolation kernel's antialiasing is not
+    reproduced bit for bit, so pixel parity is unpinned -- pass `processor=` to `VJEPA2.attach` to use another front end."""
+    x = torch.from_numpy(np.ascontiguousarray(frames)).permute(0, 3, 1, 2).float()
+    H, W = x.shape[-2:]
+    short = int(crop_size * 256 / 224)
+    scale = short / min(H, W)
+    nh, nw = max(short, int(round(H * scale))), max(short, int(round(W * scale)))
+    x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=True)
+    top, left = (nh - crop_size) // 2, (nw - crop_size) // 2
+    x = x[:, :, top:top + crop_size, left:left + crop_size] / 255.0
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return ((x - mean) / std)[None]
+
+
+class VJEPA2(HbmFeaturePlugin):
+    """The reference's video feature (video.py:56-236) on the HIP ViT-g forward: fields `name`, `layers`, `layer_aggregation`,
+    `device`, `infra`; `prepare`, `__call__ -> Tensor[L, D, T]`, `_get_data -> [41, 1408, T_event@2Hz]` per Video event (item
+    uid `filepath_offset_duration`, video.py:191-195).  Per 0.5 s step the 64 frames of the previous 4 s are decoded on the
+    host (`event.read().get_frame(t)`, moviepy in the reference), processed, and the encoder forward + token mean of all
+    41 states is one C call; `clips_per_launch` steps go through the encoder together."""
+
+    name: tp.Literal["VJEPA2"] = "VJEPA2"
+    pretrained: str = "facebook/vjepa2-vitg-fpc64-256"    # video.py:247-254; resolved from the local HF cache only
+    clips_per_launch: int = 2
+    _EVENT_TYPE: tp.ClassVar[str] = "Video"
+    _KIND: tp.ClassVar[str] = "sampled"
+    _PASS_EVENT_DURATION: tp.ClassVar[bool] = True
+    _model: tp.Any = pydantic.PrivateAttr(default=None)
+    _processor: tp.Any = pydantic.PrivateAttr(default=None)
+
+    def attach(self, model: HipVJEPA2Encoder, processor: tp.Callable[[np.ndarray], torch.Tensor] | None = None) -> "VJEPA2":
+        self._model, self._processor = model, processor
+        return self
+
+    @property
+    def model(self) -> HipVJEPA2Encoder:
+        if self._model is None:
+            from transformers import AutoModel
+
+            hf = AutoModel.from_pretrained(self.pretrained, local_files_only=True)
+            self._model = HipVJEPA2Encoder(hf.config, hf.state_dict())
+        return self._model
+
+    def _item_uid(self, event: tp.Any) -> str:
+        return f"{event.filepath}_{event.offset:.2f}_{event.duration:.2f}"
+
+    def _compute(self, events: list[tp.Any]) -> tp.Iterator[np.ndarray]:
+        from ..base import Frequency
+
+        model = self.model
+        process = self._processor or (lambda fr: default_video_processor(fr, model.crop))
+        n_frames = model.frames
+        subtimes = [k / n_frames * 4.0 for k in reversed(range(n_frames))]                  # video.py:203-205
+        for event in events:
+            video = event.read()
+            expect = Frequency(2.0).to_ind(event.duration)
+            times = np.linspace(0, video.duration, expect + 1)[1:]                          # video.py:218
+            out = np.zeros((len(times), model.depth + 1, model.dim))                        # f64, as np.zeros in video.py:230
+            for k0 in range(0, len(times), self.clips_per_launch):
+                clips = []
+                for t in times[k0:k0 + self.clips_per_launch]:
+                    frames = np.array([np.asarray(video.get_frame(max(0, t - t2))).astype("uint8") for t2 in subtimes])
+                    clips.append(process(frames))
+                means = model.hidden_state_means(torch.cat(clips, dim=0))                   # [clips, 41, dim]
+                out[k0:k0 + len(clips)] = means.cpu().numpy()
+            if hasattr(video, "close"):
+                video.close()
+            yield out.transpose(1, 2, 0)                                                    # [n_states, dim, T_event] (video.py:234)

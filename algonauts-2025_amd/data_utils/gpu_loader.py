@@ -314,7 +314,9 @@ class GpuSegmentLoader:
             raise RuntimeError(f"Failed to collate data with lengths {sorted(lens)}\nDo you need specifying padding in SegmentDataset?")
         return lens.pop()
 
-    def feature(self, spec: FeatureSpec, segments: tp.Sequence[tp.Any]) -> PackedFeature | torch.Tensor:
+    def feature(self, spec: FeatureSpec, segments: tp.Sequence[tp.Any], exact: bool = False) -> PackedFeature | torch.Tensor:
+        """One modality of a batch.  Default: the bf16 projector operand (`PackedFeature`); `exact=True`: the reference-layout
+        f32 [B, C, T] tensor with no rounding (what a feature plugin's `__call__` returns, text.py:85-124)."""
         store, dev = self.store, self.store.device
         plans = [self.plan(s, spec) for s in segments]
         B, T = len(segments), self._steps(spec, plans)
@@ -330,8 +332,11 @@ class GpuSegmentLoader:
                 idx.append(rows[order])
             np.cumsum(ptr, out=ptr)
             idx_np = np.concatenate(idx) if idx else np.zeros(0, np.int32)
-            packed = ops.word_bag(store.word_table(spec.name), torch.from_numpy(ptr.astype(np.int32)).to(dev),
-                                  torch.from_numpy(idx_np.astype(np.int32)).to(dev), B * T)
+            ptr_t, idx_t = torch.from_numpy(ptr.astype(np.int32)).to(dev), torch.from_numpy(idx_np.astype(np.int32)).to(dev)
+            if exact:
+                rows = ops.word_bag(store.word_table(spec.name), ptr_t, idx_t, B * T, f32=True)          # [B*T, C]
+                return ops.transpose_f32(rows.view(B, T, L * D))                                          # [B, C, T]
+            packed = ops.word_bag(store.word_table(spec.name), ptr_t, idx_t, B * T)
             return PackedFeature(packed, B, L, D, T)
         pieces = []
         seg_ptr = np.zeros(B + 1, dtype=np.int32)
@@ -356,7 +361,7 @@ class GpuSegmentLoader:
         pieces_t = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(dev)
         seg_t = torch.from_numpy(seg_ptr).to(dev)
         C = L * D
-        if spec.kind == "target":
+        if spec.kind == "target" or exact:
             return ops.segment_gather(pieces_t, seg_t, B, C, T, packed=False)
         return PackedFeature(ops.segment_gather(pieces_t, seg_t, B, C, T, packed=True), B, L, D, T)
 

@@ -208,6 +208,7 @@ SIGNATURES = {
     "tribe_group_mean_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, vp, vp]),
     "tribe_segment_gather_fwd": (C.c_int, [vp, vp, i64, i64, i64, vp, i32, i64, vp]),
     "tribe_word_bag_fwd": (C.c_int, [vp, i64, i64, vp, vp, i64, vp, i64, vp]),
+    "tribe_word_bag_f32_fwd": (C.c_int, [vp, i64, i64, vp, vp, i64, vp, vp]),
     "tribe_transpose_f32_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
     "tribe_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "tribe_rownorm_scale_fwd": (C.c_int, [vp, i64, i64, vp, f32, f32, vp, vp]),

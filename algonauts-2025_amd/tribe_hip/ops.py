@@ -469,14 +469,23 @@ def segment_gather(pieces: torch.Tensor, seg_ptr: torch.Tensor, B: int, C: int, 
     return out
 
 
-def word_bag(table: torch.Tensor, row_ptr: torch.Tensor, word_idx: torch.Tensor, rows: int, C_pad: int | None = None) -> torch.Tensor:
-    """table f32 [n_words, C]; CSR (row_ptr int32 [rows + 1], word_idx int32) -> bf16 [rows, C_pad] row sums."""
+def word_bag(table: torch.Tensor, row_ptr: torch.Tensor, word_idx: torch.Tensor, rows: int, C_pad: int | None = None,
+             f32: bool = False) -> torch.Tensor:
+    """table f32 [n_words, C]; CSR (row_ptr int32 [rows + 1], word_idx int32) -> bf16 [rows, C_pad] row sums
+    (f32=True: the unrounded sums, f32 [rows, C])."""
     _cuda(table, torch.float32, "table")
     _cuda(row_ptr, torch.int32, "row_ptr")
     _cuda(word_idx, torch.int32, "word_idx")
     if table.ndim != 2 or row_ptr.numel() != rows + 1:
         raise ValueError(f"word_bag: table {tuple(table.shape)}, row_ptr {tuple(row_ptr.shape)} for {rows} rows")
     n_words, C = table.shape
+    if f32:
+        out = torch.empty(rows, C, dtype=torch.float32, device=table.device)
+        if word_idx.numel() == 0:
+            return out.zero_()
+        check(lib().tribe_word_bag_f32_fwd(table.data_ptr(), n_words, C, row_ptr.data_ptr(), word_idx.data_ptr(), rows, out.data_ptr(),
+                                           _stream()), "tribe_word_bag_f32_fwd")
+        return out
     C_pad = round_up(C, 64) if C_pad is None else C_pad
     out = torch.empty(rows, C_pad, dtype=torch.bfloat16, device=table.device)
     if word_idx.numel() == 0:   # no word overlaps any row: the output is all zeros (and the kernel would get a null list)

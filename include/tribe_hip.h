@@ -156,7 +156,9 @@ int tribe_rotary_fwd(uint16_t* x, int64_t rows, int64_t T, int64_t row_stride, i
 /* softmax(q k^T * scale) v for all (batch, head); qkv as above; out bf16 [rows, heads*dim_head] */
 size_t tribe_attention_workspace_bytes(int64_t B, int64_t T, int32_t heads, int32_t dim_head);
 /* 0 (default): fused flash-style kernel for dim_head in {64,128,192,384}, else the materialised path;
- * 1: always materialise scores (QK^T GEMM -> f32 softmax -> PV GEMM), kept as a cross-check */
+ * 1: always materialise scores (QK^T GEMM -> f32 softmax -> PV GEMM), kept as a cross-check;
+ * 2: fused, but dim_head 384 on the 16-query-row kernel of the other head sizes instead of its own 32-row, one-wave-per-SIMD
+ *    kernel (A/B measurements).  Process-wide switch: set it from one thread, between launches. */
 int tribe_attention_set_mode(int32_t mode);
 int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, int32_t heads, int32_t dim_head, float scale,
                         uint16_t* out, void* workspace, size_t workspace_bytes, void* stream);
@@ -464,6 +466,11 @@ int tribe_segment_gather_fwd(const tribe_feature_piece* pieces, const int32_t* s
  * out bf16 [rows, C_pad]; lists keep the segment's event order, so the f32 sum is the reference's sum. */
 int tribe_word_bag_fwd(const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
                        int64_t rows, uint16_t* out, int64_t C_pad, void* stream);
+/* Same sums kept in f32, out f32 [rows, C]: the exact tensor a feature plugin's __call__ returns (text.py:85-124,
+ * `out += ta` over the segment's words) before any rounding; the plugin transposes it to [C, T] with
+ * tribe_transpose_f32_fwd. */
+int tribe_word_bag_f32_fwd(const float* table, int64_t n_words, int64_t C, const int32_t* row_ptr, const int32_t* word_idx,
+                           int64_t rows, float* out, void* stream);
 
 /* ---- steps after the model ------------------------------------------------------------ */
 /* out[z, c, r] = in[z, r, c], f32: predictions [B, V, T'] -> [B, T', V] rows for the submission writer

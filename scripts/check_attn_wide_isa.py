@@ -1,0 +1,37 @@
+"""Audit of the DH = 384 attention kernel's ISA (run after every edit of attention.hip; CPU only, needs hipcc):
+  * no scratch (a spilled Q fragment reloads every tile),
+  * no compiler-generated v_accvgpr_* or MFMA outside the ASMSTART / ASMEND blocks (a0..a191 hold O^T and belong to the asm
+    statements of attn_acc_regs.h; the compiler must not allocate accumulator registers of its own),
+  * prints the register budget and the instruction mix of the key loop.
+Usage: python scripts/check_attn_wide_isa.py"""
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "algonauts-2025_amd" / "csrc"
+with tempfile.TemporaryDirectory() as tmp:
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-I{CSRC}", "-save-temps", "-c",
+                    str(CSRC / "attention.hip"), "-o", f"{tmp}/attn.o"], check=True, cwd=tmp, capture_output=True)
+    text = Path(tmp, "attention-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+m = re.search(r"^(_ZN\S*attn_fwd_wide384\S*):.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+body = m.group(2)
+meta = {k: int(v) for k, v in re.findall(r"\.amdhsa_(next_free_vgpr|accum_offset|private_segment_fixed_size)\s+(\d+)", body)}
+in_asm, bad, mix = False, [], {"mfma": 0, "ds_read": 0, "global_load_lds": 0, "s_barrier": 0, "v_exp": 0}
+for ln in body.splitlines():
+    if "#ASMSTART" in ln:
+        in_asm = True
+    elif "#ASMEND" in ln:
+        in_asm = False
+    for k in mix:
+        if re.search(rf"\b{k}", ln):
+            mix[k] += 1
+    if not in_asm and re.search(r"\bv_accvgpr|\bv_mfma|scratch_", ln):
+        bad.append(ln.strip())
+print("registers:", meta, " instruction mix (whole kernel):", mix)
+if meta.get("private_segment_fixed_size", 1) or bad:
+    print("FAIL: compiler touched accumulator registers / scratch outside the asm blocks:", *bad[:10], sep="\n  ")
+    sys.exit(1)
+print("OK: no scratch, no compiler accumulator-register traffic")

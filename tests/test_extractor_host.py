@@ -70,3 +70,46 @@ def test_word_pool_windows_match_reference_slicing():
         s, n = int(start[i]), int(length[i])
         got = np.stack([np.full(2, np.arange(s, s + n).mean() + 100.0 * l) for l in range(3)])
         np.testing.assert_allclose(got, want[i], rtol=1e-6)
+
+
+def test_feature_plugin_surface_matches_the_reference_fields():
+    """text.py:42-62, audio.py:27-41, video.py:56-69: pydantic models with `name` literal, `layers`, `layer_aggregation`, `device`,
+    `infra`, extra='forbid'; prepare / __call__ / _get_data / _aggregate_layers; and no CPU compute path."""
+    import numpy as np
+    import pydantic
+    import pytest
+
+    from data_utils.events import Sound, Video, Word
+    from data_utils.features.audio import Wav2VecBert
+    from data_utils.features.text import LLAMA3p2
+    from data_utils.features.video import VJEPA2
+    from data_utils.helpers import EventTypesHelper, extract_events
+    from data_utils.segments import Segment
+
+    for cls, ev_type in ((LLAMA3p2, "Word"), (Wav2VecBert, "Sound"), (VJEPA2, "Video")):
+        f = cls()
+        assert f.name == cls.__name__ and f.layers == [0.5, 0.75, 1.0] and f.layer_aggregation == "group_mean"
+        assert f.device in ("cpu", "cuda") and f.infra.folder is None                   # "auto" resolved as the reference does
+        assert f._event_types_helper.names == [ev_type]
+        assert f._exclude_from_cache_uid() == ["device", "layers", "layer_aggregation"]
+        for m in ("prepare", "__call__", "_get_data", "_aggregate_layers"):
+            assert callable(getattr(f, m))
+        with pytest.raises(pydantic.ValidationError):
+            cls(not_a_field=1)
+        with pytest.raises(pydantic.ValidationError):
+            cls(name="Other")
+        cfg = cls(layers=[0.0, 0.5, 1.0], layer_aggregation=None, infra={"folder": "/tmp/x", "cluster": "slurm", "gpus_per_node": 1})
+        lat = np.arange(9 * 4, dtype=np.float32).reshape(9, 4)
+        assert np.array_equal(cfg._aggregate_layers(lat), lat[[0, 4, 8]])
+        assert cfg.infra.folder == "/tmp/x"
+    w, s, v = Word(start=0.0, duration=0.2, text="a"), Sound(start=0.0, duration=3.0, filepath="a.wav"), Video(start=0.0, duration=3.0, filepath="v.mkv")
+    segs = [Segment(start=0.0, duration=2.0, ns_events=[w, s, v]), Segment(start=1.0, duration=2.0, ns_events=[s, v])]
+    assert extract_events(segs, types="Sound") == [s] and extract_events(segs) == [w, s, v]
+    assert extract_events(w, types=EventTypesHelper("Word")) == [w] and extract_events([], types="Word") == []
+    assert extract_events({"type": "Word", "start": 1.0, "duration": 0.5, "text": "hi", "speaker": "x"})[0].extra == {"speaker": "x"}
+    with pytest.raises(ValueError):
+        EventTypesHelper("Nope")
+    if Wav2VecBert().device == "cpu":
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            Wav2VecBert().prepare([s])
+    assert Wav2VecBert()._item_uid(s) == "a.wav_0.00_3.00" and LLAMA3p2()._item_uid(Word(start=0, text="a", context="b a")) == "a_b a"

@@ -240,12 +240,15 @@ def test_hip_adam_late_starting_parameter_keeps_its_own_step_count():
 
 def test_fit_with_modality_dropout_runs_and_matches_torch_adam():
     """Trainer.fit WITHOUT a GradReducer at modality_dropout = 0.5 (the reference trains with 0.3, defaults.py): projectors whose
-    modality is dropped get grad None under zero_grad(set_to_none=True) and re-join later.  HipAdam must follow torch.optim.Adam
-    through the same draws (same host RNG stream => same dropped modalities)."""
+    modality is dropped get grad None under zero_grad(set_to_none=True) and re-join later; before the per-parameter step counts
+    HipAdam aborted the fit there.  The gradients every step hands to the optimiser are recorded and replayed through
+    torch.optim.Adam from the same initial weights: identical inputs, so the optimisers must agree to rounding (comparing two
+    separate fits instead is chaotic: q / k gradients of a freshly initialised encoder are ~1e-9, the size of Adam's eps)."""
     import numpy as np
 
     from algonauts2025.model import FmriEncoderConfig
     from algonauts2025.pl_module import BrainModule
+    from algonauts2025.trainer import Trainer
     from data_utils.dataloader import SegmentData
     from modeling_utils.losses.base import TorchLossConfig
     from modeling_utils.optim import HipAdam
@@ -253,39 +256,49 @@ def test_fit_with_modality_dropout_runs_and_matches_torch_adam():
     fdims = {"text": (2, 24), "audio": (2, 16), "video": (2, 20)}
     B, T, V, S = 4, 24, 30, 2
 
+    class Recording(HipAdam):
+        def __init__(self, params, **kw):
+            params = list(params)
+            super().__init__(params, **kw)
+            self.watched = params
+            self.start = [p.detach().clone() for p in params]
+            self.trace = []
+
+        def step(self, closure=None):
+            self.trace.append([None if p.grad is None else p.grad.detach().clone() for p in self.watched])
+            return super().step(closure)
+
     class _Opt:
-        def __init__(self, make):
-            self.make = make
-
         def build(self, params, total_steps=None):
-            return self.make(params)
+            return Recording(params, lr=1e-3)
 
-    def run(make_opt):
-        from algonauts2025.trainer import Trainer
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=1, heads=2, modality_dropout=0.5).build(fdims, V, T)
+    g = torch.Generator().manual_seed(3)
+    data = {m: torch.randn(B, l, d, T, generator=g) for m, (l, d) in fdims.items()}
+    data["subject_id"] = (torch.arange(B) % S).view(B, 1)
+    data["fmri"] = torch.randn(B, V, T, generator=g)
+    batch = SegmentData(data=data, segments=[None] * B)
+    module = BrainModule(model, TorchLossConfig(name="MSELoss").build(), _Opt(), {}, max_epochs=1)
+    torch.manual_seed(11)                                     # the dropout draws of the steps
+    trainer = Trainer(max_epochs=1, reduce_gradients=False)
+    trainer.fit(module, [batch] * 8)                          # raised "parameters of one group must share their step count" before
+    opt = trainer.optimizers[0]
+    assert len(opt.trace) == 8
+    absent = [sum(gr is None for gr in step) for step in opt.trace]
+    assert 0 < sum(absent) and min(absent) == 0, f"the draws must drop a modality on some steps only, got {absent}"
+    steps = {float(opt.state[p]["step"]) for p in opt.watched}
+    assert len(steps) > 1, "some projector should have taken fewer steps than the encoder"
 
-        torch.manual_seed(0)
-        np.random.seed(0)
-        model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=1, heads=2, modality_dropout=0.5).build(fdims, V, T)
-        g = torch.Generator().manual_seed(3)
-        data = {m: torch.randn(B, l, d, T, generator=g) for m, (l, d) in fdims.items()}
-        data["subject_id"] = (torch.arange(B) % S).view(B, 1)
-        data["fmri"] = torch.randn(B, V, T, generator=g)
-        batch = SegmentData(data=data, segments=[None] * B)
-        module = BrainModule(model, TorchLossConfig(name="MSELoss").build(), _Opt(make_opt), {}, max_epochs=1)
-        seen = []
-        for prm in model.projectors.parameters():
-            prm.register_hook(lambda grad, _s=seen: _s.append(1))
-        torch.manual_seed(11)                                     # the dropout draws of the steps
-        trainer = Trainer(max_epochs=1, reduce_gradients=False)
-        trainer.fit(module, [batch] * 8)
-        n_proj = len(list(model.projectors.parameters()))
-        assert 0 < len(seen) < 8 * n_proj, "the draw sequence never dropped a modality: the late-start case is not covered"
-        return {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
-
-    got = run(lambda ps: HipAdam(ps, lr=1e-3))
-    want = run(lambda ps: torch.optim.Adam(ps, lr=1e-3))
-    for n in want:
-        assert _rel(got[n], want[n]) < 1e-4, n
+    ref = [p.clone().requires_grad_() for p in opt.start]
+    opt_ref = torch.optim.Adam(ref, lr=1e-3)
+    for grads in opt.trace:
+        for p, gr in zip(ref, grads):
+            p.grad = None if gr is None else gr.clone()
+        opt_ref.step()
+    for p, q in zip(opt.watched, ref):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("Z,R,Cc,pad_c", [(3, 70, 130, 0), (2, 1024, 384, 0), (1, 33, 5, 0), (4, 64, 64, 64), (2, 257, 36, 12)])
