@@ -69,6 +69,59 @@ def allreduce_stats(stats: torch.Tensor, group: tp.Any = None) -> torch.Tensor:
     return stats
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Voxel-block sharding of the head (north star's other option, SURVEY 8e "alternative"): rank r holds
+# predictor.weights[:, :, r V/G : (r + 1) V/G] and computes its [B, V/G, T'] slab from REPLICATED encoder latents; the slabs are
+# all-gathered along V.  It shards 0.3 % of the forward FLOPs (the encoder stays replicated), so sequence data parallelism is
+# the default and this is for outputs far wider than 1000 parcels (whole-brain voxels), where the [S, C, V] weights and the
+# [B, V, T'] predictions are what no longer fit or what dominates.
+# ---------------------------------------------------------------------------------------------------------------------
+def voxel_slice(n_outputs: int, rank: int, world_size: int) -> slice:
+    """Contiguous block of output channels owned by `rank`: ceil-sized blocks, the last one possibly shorter (or empty)."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    per = -(-n_outputs // world_size)
+    return slice(min(rank * per, n_outputs), min((rank + 1) * per, n_outputs))
+
+
+def shard_voxel_head(predictor: tp.Any, rank: int, world_size: int) -> tp.Any:
+    """A `SubjectLayers` holding only this rank's block of output channels (parameters are copies of the slices; the full head's
+    `state_dict` stays the checkpoint format -- re-assemble with `torch.cat(..., dim=2)` over ranks)."""
+    from modeling_utils.models.common import SubjectLayers
+
+    S, Cc, V = predictor.weights.shape
+    sl = voxel_slice(V, rank, world_size)
+    if sl.stop <= sl.start:
+        raise ValueError(f"rank {rank} of {world_size} owns no output channel of {V}")
+    part = SubjectLayers(in_channels=Cc, out_channels=sl.stop - sl.start, n_subjects=S, bias=predictor.bias is not None,
+                         average_subjects=predictor.average_subjects)
+    with torch.no_grad():
+        part.weights.copy_(predictor.weights[:, :, sl])
+        if predictor.bias is not None:
+            part.bias.copy_(predictor.bias[:, sl])
+    return part.to(predictor.weights.device)
+
+
+def gather_voxel_slabs(slab: torch.Tensor, n_outputs: int, group: tp.Any = None) -> torch.Tensor:
+    """All-gather [B, V_r, T'] slabs along V into [B, n_outputs, T'] (every rank gets the full predictions).  Slabs are padded
+    to the common block size for the collective (equal message sizes) and the padding is dropped afterwards."""
+    rank, ws = world()
+    if ws == 1:
+        return slab
+    per = -(-n_outputs // ws)
+    slab = slab.detach()                       # a collective is not differentiable; predictions are gathered for evaluation
+    B, Vr, Tn = slab.shape
+    if Vr != voxel_slice(n_outputs, rank, ws).stop - voxel_slice(n_outputs, rank, ws).start:
+        raise ValueError(f"rank {rank}: slab of {Vr} channels does not match its block of {n_outputs} over {ws} ranks")
+    send = slab if Vr == per else torch.nn.functional.pad(slab, (0, 0, 0, per - Vr))
+    buf = torch.empty(ws * B, per, Tn, dtype=slab.dtype, device=slab.device)     # rank-major along dim 0
+    if dist.get_backend(group) == "gloo" and slab.is_cuda:
+        dist.all_gather(list(buf.chunk(ws, dim=0)), send.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    return buf.view(ws, B, per, Tn).permute(1, 0, 2, 3).reshape(B, ws * per, Tn)[:, :n_outputs].contiguous()
+
+
 class GradReducer:
     """Gradient averaging of the data-parallel training step: the job Lightning's DDP strategy does for the reference
     (main.py:388-395, `ddp_find_unused_parameters_true`), laid out for xGMI.

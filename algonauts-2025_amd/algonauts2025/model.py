@@ -199,14 +199,18 @@ class FmriEncoder(nn.Module):
         from modeling_utils import autograd as ag
 
         cfg = self.config
-        if cfg.feature_aggregation != "cat":
-            raise NotImplementedError("the training path implements feature_aggregation='cat' (the reference default)")
+        cat = cfg.feature_aggregation == "cat"
         for modality in data.keys():
             if modality in self.feature_dims:
                 break
         ref = data[modality]
         B, T = ref.shape[0], ref.shape[-1]
-        n_mod, slot = len(self.feature_dims), self.hidden // len(self.feature_dims)
+        n_mod = len(self.feature_dims)
+        slot = self.hidden // n_mod if cat else self.hidden
+        if not cat and any(m not in self.projectors for m in self.feature_dims):
+            # reference behaviour: a hidden // n zero block cannot be summed with hidden-wide projections (model.py:143-144,163-164)
+            raise RuntimeError(f"The size of tensor a ({self.hidden}) must match the size of tensor b ({self.hidden // n_mod}) "
+                               "at non-singleton dimension 2")
         dropped = self._draw_modality_dropout()
         slices = []
         for m in self.feature_dims.keys():
@@ -216,7 +220,13 @@ class FmriEncoder(nn.Module):
             packed = self._pack(data[m])
             lin = self.projectors[m]
             slices.append(ag.ProjectorFuse.apply(packed, lin.weight, lin.bias))
-        x = torch.cat(slices, dim=1).view(B, T, n_mod * slot)
+        if cat:
+            x = torch.cat(slices, dim=1).view(B, T, n_mod * slot)   # model.py:161-162
+        else:
+            x = slices[0]
+            for extra in slices[1:]:                                # model.py:163-164: sum(tensors)
+                x = x + extra
+            x = x.view(B, T, slot)
         x = x + self.time_pos_embed[:, :T]                      # model.py:169-170 (autograd sums the rows over the batch)
         subject_id = data["subject_id"]
         if hasattr(self, "subject_embed"):
@@ -230,8 +240,7 @@ class FmriEncoder(nn.Module):
             norms_a, attn, res_a = enc.layers[2 * i]
             norms_f, ff, res_f = enc.layers[2 * i + 1]
             xn = ag.ScaleNorm.apply(x, norms_a[0].g, gs, eps)
-            wqkv = torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], dim=0)
-            qkv = ag.Linear.apply(xn, wqkv, None, None, None, False)
+            qkv = ag.QKVLinear.apply(xn, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
             if enc.rotary_emb_dim:
                 qkv = ag.Rotary.apply(qkv, cos, sin, T, enc.heads, enc.dim_head, enc.rotary_emb_dim, enc.rotary_interleaved)
             ao = ag.Attention.apply(qkv, B, T, enc.heads, enc.dim_head, scale)
@@ -309,11 +318,13 @@ class FmriEncoder(nn.Module):
             if modality not in self.contrastive_heads or modality not in data:
                 continue
             feat = data[modality]
-            if feat.shape[-1] != T:
-                raise NotImplementedError("contrastive training with a modality at a different time resolution")
             packed = self._pack(feat)
             head = self.contrastive_heads[modality]
-            lat = ag.ProjectorFuse.apply(packed, head.weight, head.bias)
+            lat = ag.ProjectorFuse.apply(packed, head.weight, head.bias)            # f32 [B * T_mod, hidden]
+            T_mod = feat.shape[-1]
+            if T_mod != T:   # model.py:234-238: adaptive average pool of the modality latents to the brain's time axis
+                lat = lat.view(B, T_mod, -1).transpose(1, 2).contiguous()           # [B, hidden, T_mod]
+                lat = ag.AdaptivePool.apply(lat, T).transpose(1, 2).reshape(B * T, -1).contiguous()
             losses[modality] = ag.InfoNCE.apply(brain, lat, self.config.contrastive_temperature)
         return losses
 

@@ -151,6 +151,70 @@ class Linear(torch.autograd.Function):
         return dx, dw, db, dres, drs, None
 
 
+class _FusedQKVPacks:
+    """bf16 [3N, K] (q | k | v rows) and its transpose [K, 3N] for one attention block, rebuilt only when one of the three f32
+    weights was written (optimizer step): each weight is packed STRAIGHT into its row slice -- no f32 `torch.cat` of the three
+    matrices per layer and step (113 MB written + read back, plus the split in backward), which model.py:228 of round 1 did."""
+
+    def __init__(self) -> None:
+        self._c: dict[int, tuple[tp.Any, tuple, torch.Tensor, torch.Tensor]] = {}
+
+    def get(self, ws: tuple[torch.Tensor, torch.Tensor, torch.Tensor]) -> tuple[torch.Tensor, torch.Tensor]:
+        import weakref
+
+        key = id(ws[0])
+        sig = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in ws)
+        hit = self._c.get(key)
+        if hit is None or hit[0]() is not ws[0] or hit[1] != sig:
+            N, K = ws[0].shape
+            if any(tuple(w.shape) != (N, K) for w in ws) or K % 64:
+                raise ValueError("fused q|k|v projection: the three weights must share one [N, K] shape with K % 64 == 0")
+            fused = torch.empty(3 * N, K, dtype=torch.bfloat16, device=ws[0].device)
+            for i, w in enumerate(ws):
+                wd = w.detach().contiguous()
+                check(lib().tribe_pack_weight_bf16(wd.data_ptr(), N, K, K, fused[i * N:(i + 1) * N].data_ptr(), N, K, _s()), "tribe_pack_weight_bf16")
+            hit = (weakref.ref(ws[0], lambda _r, k=key: self._c.pop(k, None)), sig, fused, transpose_bf16(fused, 1, 3 * N, K, 0, K)[0])
+            self._c[key] = hit
+        return hit[2], hit[3]
+
+
+QKV_PACKS = _FusedQKVPacks()
+
+
+class QKVLinear(torch.autograd.Function):
+    """qkv = x [Wq; Wk; Wv]^T as ONE GEMM (x bf16 [M, K] -> bf16 [M, 3N]); backward: dx = dqkv W and ONE wgrad GEMM whose
+    [3N, K] result is handed back as three row slices (views: no copy)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        M, K = x.shape
+        N = wq.shape[0]
+        wp, _ = QKV_PACKS.get((wq, wk, wv))
+        y = torch.empty(M, 3 * N, dtype=torch.bfloat16, device=x.device)
+        _gemm(x, wp, y, lda=K, ldb=K, ldc=3 * N, M=M, N=3 * N, K=K, role=2)
+        ctx.save_for_backward(x, wq, wk, wv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq, wk, wv = ctx.saved_tensors
+        M, K = x.shape
+        N = wq.shape[0]
+        _, wt = QKV_PACKS.get((wq, wk, wv))                     # [K, 3N_pad64]
+        dpre = cast_bf16(dy.contiguous())
+        N3, Np = 3 * N, wt.shape[1]
+        if Np != N3:
+            dpre = torch.nn.functional.pad(dpre, (0, Np - N3))
+        dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+        _gemm(dpre, wt, dx, lda=Np, ldb=Np, ldc=K, M=M, N=K, K=Np)
+        dpre_t = transpose_bf16(dpre, 1, M, N3, 0, Np)[0]       # [3N, M_pad]
+        x_t = transpose_bf16(x, 1, M, K, 0, K)[0]               # [K, M_pad]
+        Mp = dpre_t.shape[1]
+        dw = torch.empty(N3, K, dtype=torch.float32, device=x.device)
+        _gemm(dpre_t, x_t, dw, lda=Mp, ldb=Mp, ldc=K, M=N3, N=K, K=Mp)
+        return dx, dw[:N], dw[N:2 * N], dw[2 * N:]
+
+
 class FeedForward(torch.autograd.Function):
     """out = gelu(x W1^T + b1) W2^T + b2 + res * res_scale  (x_transformers FeedForward + scaled residual).
     x bf16 [M, D]; res f32 [M, D] (the block input); out f32 [M, D]."""

@@ -241,3 +241,55 @@ def test_optimizer_configs_mirror_the_reference_block():
                 {"optimizer": {"name": "Adam", "lr": 1e-4}, "extra_field": 1}):
         with pytest.raises(pydantic.ValidationError):
             LightningOptimizerConfig(**bad)
+
+
+def _voxel_worker(rank: int, world: int, port: int, q):
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "algonauts-2025_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from algonauts2025 import distributed as D
+
+        S, Cc, V, B, T = 3, 16, 13, 5, 9                      # 13 parcels over 2 ranks: blocks of 7 and 6
+        g = torch.Generator().manual_seed(3)
+        full = tribe_ref.SubjectLayersRef(Cc, V, S, bias=True)
+        with torch.no_grad():
+            full.weights.copy_(torch.randn(S, Cc, V, generator=g))
+            full.bias.copy_(torch.randn(S, V, generator=g))
+        x = torch.randn(B, Cc, T, generator=g)                # replicated encoder latents [B, C, T]
+        subj = torch.tensor([[0], [2], [1], [1], [0]])
+        want = full(x, subj)                                  # [B, V, T]
+        sl = D.voxel_slice(V, rank, world)
+        part = tribe_ref.SubjectLayersRef(Cc, sl.stop - sl.start, S, bias=True)   # the arithmetic the GPU head does on its block
+        with torch.no_grad():
+            part.weights.copy_(full.weights[:, :, sl])
+            part.bias.copy_(full.bias[:, sl])
+        got = D.gather_voxel_slabs(part(x, subj), V)
+        q.put((rank, tuple(got.shape) == (B, V, T), bool(torch.equal(got, want)), (sl.start, sl.stop)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_voxel_block_head_split_two_ranks():
+    """north star's 'voxel-blocks shard across the GPUs with an all-gather of predictions': each rank computes its block of
+    parcels from replicated latents, the slabs are gathered along V (uneven blocks padded for the collective)."""
+    from algonauts2025 import distributed as D
+
+    assert [(D.voxel_slice(1000, r, 8).start, D.voxel_slice(1000, r, 8).stop) for r in (0, 7)] == [(0, 125), (875, 1000)]
+    assert [D.voxel_slice(5, r, 4).stop - D.voxel_slice(5, r, 4).start for r in range(4)] == [2, 2, 1, 0]
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_voxel_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[3] for r in results] == [(0, 7), (7, 13)]
+    assert all(r[1] and r[2] for r in results), results

@@ -79,7 +79,7 @@ def test_autograd_blocks_vs_torch():
     torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("cfg_kw", [{}, {"layer_aggregation": "mean", "subject_embedding": True}])
+@pytest.mark.parametrize("cfg_kw", [{}, {"layer_aggregation": "mean", "subject_embedding": True}, {"feature_aggregation": "sum"}])
 def test_training_step_gradients_vs_oracle(cfg_kw):
     """BrainModule.training_step + loss.backward(): loss and every parameter gradient vs the fp32 CPU oracle graph."""
     from algonauts2025.model import FmriEncoderConfig
@@ -91,6 +91,7 @@ def test_training_step_gradients_vs_oracle(cfg_kw):
     V, Tout, S, B, T = 50, 10, 3, 4, 31
     dims = tribe_ref.EncoderDims(hidden=768, depth=2, heads=4)
     ref = tribe_ref.FmriEncoderRef(fdims, V, Tout, S, layer_aggregation=cfg_kw.get("layer_aggregation", "cat"),
+                                   feature_aggregation=cfg_kw.get("feature_aggregation", "cat"),
                                    subject_embedding=cfg_kw.get("subject_embedding", False), dims=dims).train()
     with torch.no_grad():
         tribe_ref.fill_params_(ref, seed=2)
