@@ -22,7 +22,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // bands of GM = 4 tile rows column by column, so the ~32 workgroups an XCD runs at once form a 4 x 8 patch
 // that shares 4 A panels and 8 B panels in that XCD's L2 (instead of 1 + 32 with a plain row-major walk).
 __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-  constexpr int GM = 4;
+#ifndef TRIBE_GEMM_BAND_ROWS
+#define TRIBE_GEMM_BAND_ROWS 4   // scripts/gemm_band_experiment.py builds 2 / 8 / 16 for the L2-reuse experiment of DESIGN 4.1
+#endif
+  constexpr int GM = TRIBE_GEMM_BAND_ROWS;
   const int tile = xcd_remap(bid, tiles_m * tiles_n);
   const int band = tile / (GM * tiles_n);
   const int first_m = band * GM;

@@ -303,3 +303,75 @@ def test_nearest_index_matches_interpolate():
         x = torch.arange(t_in, dtype=torch.float32)[None, None]
         want = torch.nn.functional.interpolate(x, t_out)[0, 0].to(torch.int64)
         assert torch.equal(nearest_index(t_in, t_out), want), (t_in, t_out)
+
+
+# ---- parity at the REAL layer counts ------------------------------------------------------------------------------------
+# The tests above stop at 2-3 layers; the features the encoder consumes are group means over the upper half of 28 / 24 / 40
+# layers (layers [0.5, 0.75, 1.0], text.py:129-149), so the bf16 kernels' error has to stay small through the whole stack.
+# Depth is the real one, random weights at the libraries' default init; widths and sequences are reduced so that the fp32
+# transformers model on the CPU (the reference route) runs in seconds.  Every state is checked and the growth is printed
+# (pytest -s) -- scripts/extractor_bench.py records the same curve at full width against its own f32-free bf16 baseline.
+def _depth_curve(got, want):
+    return [_rel(got[s], want[s]) for s in range(len(want))]
+
+
+def test_llama_parity_at_28_layers():
+    from data_utils.features.text import HipLlamaModel, word_pool_windows
+
+    cfg, hf = _tiny_llama(layers=28, hidden=1024, heads=8, kv=4, head_dim=128, inter=2048, vocab=400)
+    pad_id, B, T = 7, 3, 96
+    g = torch.Generator().manual_seed(21)
+    ids = torch.randint(8, cfg.vocab_size, (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.long)
+    for i, n in enumerate([96, 61, 17]):
+        ids[i, n:] = pad_id
+        mask[i, n:] = 0
+    words = ["alpha", "be", "gamma-delta"]
+    want = np.stack(extractors_ref.llama_word_states(hf, ids, mask, words, pad_id), axis=1)        # [n_states, B, dim]
+    model = HipLlamaModel(cfg, hf.state_dict())
+    start, length = word_pool_windows(ids, words, pad_id)
+    got = model.forward_pooled(ids, start, length).cpu().numpy()
+    curve = _depth_curve(got, want)
+    print("llama 28 layers, per-state relative L2:", [f"{e:.1e}" for e in curve[::4]])
+    assert got.shape == want.shape == (29, B, 1024)
+    assert max(curve) < 2.5e-2, f"worst state {int(np.argmax(curve))}: {max(curve):.2e}"
+    # what the model consumes: the two layer groups of layers = [0.5, 0.75, 1.0] -> means over states 14..20 and 21..28
+    for lo, hi in ((14, 21), (21, 29)):
+        assert _rel(got[lo:hi].mean(0), want[lo:hi].mean(0)) < 2e-2
+
+
+def test_w2vbert_parity_at_24_layers():
+    from data_utils.features.audio import HipWav2Vec2Bert
+
+    cfg, hf = _tiny_w2vbert(hidden=512, heads=8, layers=24, inter=1024)
+    g = torch.Generator().manual_seed(22)
+    T, n_out = 250, 10
+    feats = torch.randn(1, T, 160, generator=g)
+    with torch.no_grad():
+        out = hf(feats, output_hidden_states=True)
+    want = torch.nn.functional.interpolate(torch.stack(out.hidden_states).squeeze(1).transpose(-1, -2), n_out).numpy()
+    got = HipWav2Vec2Bert(cfg, hf.state_dict()).hidden_states_resampled(feats, n_out).cpu().numpy()[0]
+    curve = _depth_curve(got, want)
+    print("w2v-bert 24 layers, per-state relative L2:", [f"{e:.1e}" for e in curve[::4]])
+    assert got.shape == want.shape == (25, 512, n_out)
+    assert max(curve) < 3e-2, f"worst state {int(np.argmax(curve))}: {max(curve):.2e}"
+    for lo, hi in ((12, 18), (18, 25)):
+        assert _rel(got[lo:hi].mean(0), want[lo:hi].mean(0)) < 2.5e-2
+
+
+def test_vjepa2_parity_at_40_layers():
+    from data_utils.features.video import HipVJEPA2Encoder
+
+    cfg, hf = _tiny_vjepa2(hidden=384, heads=6, layers=40, mlp_ratio=4.0, crop=64, frames=8)
+    g = torch.Generator().manual_seed(23)
+    clips = torch.randn(1, cfg.frames_per_clip, 3, cfg.crop_size, cfg.crop_size, generator=g)
+    with torch.no_grad():
+        out = hf(pixel_values_videos=clips, output_hidden_states=True, skip_predictor=True)
+    want = torch.cat([x.unsqueeze(1) for x in out.hidden_states], dim=1).mean(dim=2)[0].numpy()   # [n_states, dim]
+    got = HipVJEPA2Encoder(cfg, hf.state_dict()).hidden_state_means(clips).cpu().numpy()[0]
+    curve = _depth_curve(got, want)
+    print("v-jepa2 40 layers, per-state relative L2:", [f"{e:.1e}" for e in curve[::5]])
+    assert got.shape == want.shape == (41, 384)
+    assert max(curve) < 3e-2, f"worst state {int(np.argmax(curve))}: {max(curve):.2e}"
+    for lo, hi in ((20, 30), (30, 41)):
+        assert _rel(got[lo:hi].mean(0), want[lo:hi].mean(0)) < 2.5e-2
