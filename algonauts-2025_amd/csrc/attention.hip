@@ -52,7 +52,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lptr_t)p; }
-
 // keys per staged tile = 32 * NSUB: small heads take several 32-key sub-tiles per barrier / softmax pass so that the
 // fixed per-tile cost (barrier, max exchange, rescale test) is amortised over the same number of MFMAs as at DH = 384
 template <int DH>
@@ -675,6 +674,264 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wide384_kernel(const AttnArgs
   });
 }
 
+// =====================================================================================================================
+// DH = 384, bidirectional, KEY-SPLIT variant: 8 waves = two per SIMD.
+//
+// The one-wave-per-SIMD kernel above pays for every LDS-DMA piece with ~105 cycles of its single in-order instruction stream
+// (stamps: 12 pieces per tile = 1260 of 3770 cycles; bursts, even spreading, early issue, per-wave skew and a buffer descriptor
+// all cost the same) because nothing else can issue on the SIMD meanwhile.  Two waves per SIMD hide that under the partner's
+// MFMAs, but a wave then has 256 registers, too few for 32 query rows x 384 (O^T alone is 192).  So the head dimension is split
+// between the two waves of a pair: wave (j, c) owns query block j (32 rows) and the half c of the head dimension whose 128-byte
+// chunk index ((d >> 6) & 1) equals c:
+//   * S^T partial = K[:, half c] . Q^T[half c]: 12 MFMAs; the partials are exchanged through LDS (4 KiB per wave, f32) and
+//     summed, so both waves hold the same full S^T (a + b == b + a in IEEE) and run the same softmax;
+//   * O^T[half c] += V^T[half c] . P^T: 12 MFMAs into 6 accumulator tiles (96 AGPRs); Q^T[half c] sits in 32 more AGPRs (MFMA B
+//     operands may be accumulator registers; 8 of the 12 fragments, a[96:127], the other 4 in VGPRs), 128 VGPRs for the rest.
+// MEASURED (profiles/r02_g_attn_bench.json): 1.14 ms at B = 64, the same as the one-wave kernel (1.13-1.16 ms), and neither an
+// L2 warm-up of the K / V lines four tiles ahead nor buffer-descriptor DMA moved either kernel.  All three structures (16-row
+// 1.28 ms) sit near one line: a workgroup of 128 queries streams 48 KiB of K / V per 32-key tile, the LDS rings leave about one
+// tile (48 KiB) in flight, and at the ~2 us loaded L2 latency of this access pattern that is ~24 GB/s per CU = 2.1 us per tile
+// (the 256^2 GEMM keeps 80 KiB in flight and streams 38 GB/s per CU).  More bytes in flight need LDS that a DH = 384 tile does
+// not leave (160 KiB - 48 KiB working set); this kernel is kept as the selectable variant (tribe_attention_set_mode(3)).
+// Same LDS image, operand maps and AGPR ownership rules as the kernel above.  K ring 2 slots, V ring 3 slots, exchange buffer
+// 32 KiB: 152 KiB.  One barrier per tile, between the partial S^T and the softmax (it publishes the partials AND tile t + 1).
+struct KSplitCfg {
+  static constexpr int DH = 384, ROWB = 768, KV = 32, CHUNKS = 48;
+  static constexpr int KS = 12, NT = 6, Q_AGPR = 8;    // k-steps of 16 and 32-row O^T tiles PER WAVE; Q^T fragments kept in AGPRs
+  static constexpr int TILE_BYTES = KV * ROWB;
+  static constexpr int WAVES = 8, PPW = 3;             // 24 pieces per K or V tile, 3 per wave
+  static constexpr int K_SLOTS = 2, V_SLOTS = 3;
+  static constexpr int V_BASE = K_SLOTS * TILE_BYTES;
+  static constexpr int X_BASE = (K_SLOTS + V_SLOTS) * TILE_BYTES;   // exchange buffer: 8 waves x 4 KiB
+  static constexpr int SMEM = X_BASE + WAVES * 4096;   // 152 KiB
+  static constexpr int DEPTH = 4;
+};
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_ksplit384_kernel(const AttnArgs a) {
+  using C = KSplitCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qj = wave & 3, c = wave >> 2;              // query block, head-dimension half
+  const int r31 = lane & 31, h = lane >> 5;
+
+  const int T = a.T;
+  const float scale_log2e = a.scale_log2e;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int qb = slot % a.qblocks;
+  const int pair = (slot / a.qblocks) * 8 + xcd;
+  if (pair >= a.n_bh) return;
+  const int hd = pair % a.heads_q;
+  const int b = pair / a.heads_q;
+  const int hk = hd / a.group;
+  const int64_t ld = a.ld_kv;
+  const unsigned short* qbase = a.q + (int64_t)b * T * a.ld_q + (int64_t)hd * C::DH;
+  const unsigned short* kbase = a.k + (int64_t)b * T * ld + (int64_t)hk * C::DH;
+  const unsigned short* vbase = a.v + (int64_t)b * T * ld + (int64_t)hk * C::DH;
+
+  // ---- Q^T fragments of this wave's half: local k-step k' = 4 s + i is global k-step 8 s + 4 c + i (d = 16 ks + 8 h ..) ----
+  const int q0 = qb * 128 + qj * 32;
+  const int qrow = (q0 + r31 < T) ? q0 + r31 : T - 1;
+  bf16x8_t qv[C::KS - C::Q_AGPR];   // a wave at two per SIMD addresses 128 accumulator registers: 8 fragments there, 4 in VGPRs
+  static_for<0, C::KS>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int ksg = 8 * (k >> 2) + 4 * c + (k & 3);
+    const bf16x8_t qfrag = *(const bf16x8_t*)(qbase + (int64_t)qrow * a.ld_q + ksg * 16 + h * 8);
+    if constexpr (k < C::Q_AGPR) QFrag<k>::set(qfrag);
+    else qv[k - C::Q_AGPR] = qfrag;
+  });
+  static_for<0, C::NT>([&](auto n) { AccTile<decltype(n)::value>::zero(); });
+  asm volatile("s_nop 7" ::: "memory");   // v_accvgpr_write -> MFMA operand
+
+  // ---- staging plan: piece i of this wave covers linear 16-byte chunks [(wave + 8 i) * 64, +64) of a tile ----
+  int st_off[C::PPW];
+#pragma unroll
+  for (int i = 0; i < C::PPW; ++i) {
+    const int p = (wave + C::WAVES * i) * 64 + lane;
+    st_off[i] = (p / C::CHUNKS) * (int)ld + swz_wide(p % C::CHUNKS, p / C::CHUNKS) * 8;
+  }
+  auto stage_piece = [&](int which, int slot_i, int key0, int i) {
+    const unsigned short* src = (which ? vbase : kbase) + (int64_t)key0 * ld;
+    const int piece = wave + C::WAVES * i;
+    int off = st_off[i];
+    if (key0 + C::KV > T) {   // tail keys re-read the last valid row; they are masked to -inf in the softmax
+      const int p = piece * 64 + lane;
+      const int row0 = p / C::CHUNKS;
+      const int row = (key0 + row0 < T) ? row0 : T - 1 - key0;
+      off = row * (int)ld + swz_wide(p % C::CHUNKS, row0) * 8;
+    }
+    glds16(src + off, lds_addr(smem) + (which ? C::V_BASE : 0) + slot_i * C::TILE_BYTES + piece * 1024);
+  };
+
+  // ---- per-lane LDS read offsets: K row reads (4 registers: chunk = 16 s + 8 c + 2 i + h) and V transposed reads (4 registers:
+  // d-tile dt = 4 u + 2 c + e, chunk = 4 (2 c + e) + 2 g1 + pp inside segment u) ----
+  int ka[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ka[i] = r31 * C::ROWB + swz_wide(8 * c + 2 * i + h, r31) * 16;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
+  int va[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int lh = 0; lh < 2; ++lh) {
+      const int row = 4 * h + tq + 8 * lh;
+      va[e][lh] = C::V_BASE + row * C::ROWB + swz_wide(4 * (2 * c + e) + 2 * g1 + (tp >> 1), row) * 16 + (tp & 1) * 8;
+    }
+  auto ld_k = [&](int k) -> bf16x8_t { return *(const bf16x8_t*)(smem + ka[k & 3] + (k >> 2) * 256); };
+  auto ld_v = [&](int i) -> bf16x8_t {   // fragment i = 6 s_key + n, tile n = 2 u + e
+    const int sk = i / C::NT, n = i % C::NT;
+    const int imm = (n >> 1) * 256 + sk * 16 * C::ROWB;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[n & 1][0] + imm));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[n & 1][1] + imm));
+    bf16x8_t vf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+    return vf;
+  };
+  const int x_mine = C::X_BASE + wave * 4096 + lane * 16, x_peer = C::X_BASE + (wave ^ 4) * 4096 + lane * 16;
+
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (T + C::KV - 1) / C::KV;
+#pragma unroll
+  for (int i = 0; i < C::PPW; ++i) { stage_piece(0, 0, 0, i); stage_piece(1, 0, 0, i); }
+  if (ntiles > 1) {
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) { stage_piece(0, 1, C::KV, i); stage_piece(1, 1, C::KV, i); }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8_t kf[C::KS], vf[2 * C::NT];
+#pragma unroll
+  for (int d = 0; d < C::DEPTH; ++d) kf[d] = ld_k(d);
+
+  int vcur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    // ---- partial S^T over this wave's half of the head dimension ----
+    f32x16_t s;
+    static_for<0, C::KS>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k + C::DEPTH < C::KS) kf[k + C::DEPTH] = ld_k(k + C::DEPTH);
+      else vf[k + C::DEPTH - C::KS] = ld_v(k + C::DEPTH - C::KS);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k == 0) QFrag<k>::mfma_first(s, kf[k]);
+      else if constexpr (k < C::Q_AGPR) QFrag<k>::mfma(s, kf[k]);
+      else mfma_s(s, kf[k], qv[k - C::Q_AGPR]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 11" : "+v"(s));
+    // ---- hand the partial to the partner wave (the other half of the head dimension, same query block) ----
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) *(f32x4_t*)(smem + x_mine + q4 * 1024) = f32x4_t{s[4 * q4], s[4 * q4 + 1], s[4 * q4 + 2], s[4 * q4 + 3]};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my K(t + 1) / V(t + 1) pieces and my partial have landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4_t o4 = *(const f32x4_t*)(smem + x_peer + q4 * 1024);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[4 * q4 + e] += o4[e];
+    }
+
+    // ---- online softmax (identical in both waves of the pair) ----
+    if ((t + 1) * C::KV > T) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (t * C::KV + (r & 3) + 8 * (r >> 2) + 4 * h >= T) s[r] = -INFINITY;
+    }
+    float pmax = max3f(s[0], s[1], s[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) pmax = max3f(pmax, s[r], s[r + 1]);
+    pmax = fmaxf(pmax, s[15]);
+    pmax = pair_max(pmax) * scale_log2e;
+    if (!__all(pmax - m_run <= 8.0f)) {
+      const float m_new = fmaxf(m_run, pmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+      if (t > 0) {
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        static_for<0, C::NT>([&](auto n) { AccTile<decltype(n)::value>::scale(alpha); });
+        asm volatile("s_nop 7" ::: "memory");
+      }
+    }
+    bf16x8_t pf[2];
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_run));
+      psum += p;
+      pf[r >> 3][r & 7] = (short)f32_to_bf16(p);
+    }
+    l_run += psum;
+
+    const bool more = t + 2 < ntiles;
+    const int kslot = t & 1;                                    // K(t + 2) replaces K(t); K(t + 1) sits in the other slot
+    const int vnext2 = vcur == 0 ? 2 : vcur - 1;                // (vcur + 2) % 3: the slot V(t - 1) left
+    const int kstep = kslot ? -C::TILE_BYTES : C::TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(ka[i]) : "s"(kstep));
+    asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));
+
+    // ---- O^T[half c] += V^T[half c] . P^T; this wave's 6 LDS-DMA pieces of tile t + 2 and the first K fragments of tile t + 1
+    // ride along (the partner wave's MFMAs cover their issue time) ----
+    static_for<0, 2 * C::NT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + C::DEPTH < 2 * C::NT) vf[i + C::DEPTH] = ld_v(i + C::DEPTH);
+      else kf[i + C::DEPTH - 2 * C::NT] = ld_k(i + C::DEPTH - 2 * C::NT);
+      if constexpr (i % 2 == 1 && i / 2 < 2 * C::PPW) {
+        if (more) stage_piece((i / 2) & 1, (i / 2) & 1 ? vnext2 : kslot, (t + 2) * C::KV, i / 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      AccTile<i % C::NT>::mfma(vf[i], pf[i / C::NT]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    const int vstep = (vcur == C::V_SLOTS - 1) ? -(C::V_SLOTS - 1) * C::TILE_BYTES : C::TILE_BYTES;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      asm volatile("v_add_u32 %0, %1, %0" : "+v"(va[e][0]) : "s"(vstep));
+      asm volatile("v_add_u32 %0, %1, %0" : "+v"(va[e][1]) : "s"(vstep));
+    }
+    vcur = (vcur == C::V_SLOTS - 1) ? 0 : vcur + 1;
+  }
+
+  // ---- normalise and write this wave's half: tile n = 2 u + e holds d = 32 (4 u + 2 c + e) + (r & 3) + 8 (r >> 2) + 4 h ----
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  const float inv = 1.0f / pair_sum(l_run);
+  const int q = q0 + r31;
+  unsigned short* orow = a.out + ((int64_t)b * T + (q < T ? q : T - 1)) * a.ld_out + (int64_t)hd * C::DH + 4 * h + 64 * c;
+  static_for<0, C::NT>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    float ov[16];
+    AccTile<n>::read(ov);
+    if (q < T) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16x4_t pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = f32_to_bf16(ov[4 * g + e] * inv);
+        *(u16x4_t*)(orow + 128 * (n >> 1) + 32 * (n & 1) + 8 * g) = pk;
+      }
+    }
+  });
+}
+
+int launch_attn_ksplit384(const AttnArgs& a, int64_t B, hipStream_t s) {
+  using C = KSplitCfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_ksplit384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr_done = true;
+  }
+  const int64_t nblocks = (B * a.heads_q + 7) / 8 * 8 * a.qblocks;
+  if (nblocks >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: grid too large"); return -1; }
+  if ((int64_t)a.T * a.ld_kv >= (1ll << 31)) { tribe_set_error("tribe_attention_fwd: sequence too long for 32-bit offsets"); return -1; }
+  hipLaunchKernelGGL(attn_fwd_ksplit384_kernel, dim3((unsigned)nblocks), dim3(512), C::SMEM, s, a);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_attn_wide384(const AttnArgs& a, int64_t B, hipStream_t s) {
   using C = WideCfg;
   static bool attr_done = false;
@@ -706,11 +963,12 @@ int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
   return 0;
 }
 
-int g_attn_wide384 = 1;   // 0: run DH = 384 on the 16-row kernel (A/B measurements, tribe_attention_set_mode(2))
+int g_attn_wide384 = 1;   // DH = 384 variant: 1 = one wave per SIMD (32 rows x 384), 2 = key-split pairs, 0 = the 16-row kernel (tribe_attention_set_mode)
 
 template <int DH>
 int launch_attn_dh(const AttnArgs& a, int64_t B, int causal, hipStream_t s) {
-  if (DH == 384 && !causal && g_attn_wide384) return launch_attn_wide384(a, B, s);
+  if (DH == 384 && !causal && g_attn_wide384 == 1) return launch_attn_wide384(a, B, s);
+  if (DH == 384 && !causal && g_attn_wide384 == 2) return launch_attn_ksplit384(a, B, s);
   return causal ? launch_attn<DH, 1, 0>(a, B, s) : launch_attn<DH, 0, 0>(a, B, s);
 }
 

@@ -16,8 +16,8 @@ int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, in
 void tribe_internal_attention_set_wide384(int on);
 static int g_attn_mode = 0;  // 0 = fused kernel when the head size has one, 1 = always the 3-kernel (materialised) path
 extern "C" int tribe_attention_set_mode(int32_t mode) {
-  TRIBE_REQUIRE(mode >= 0 && mode <= 2, "tribe_attention_set_mode: mode must be 0 (auto), 1 (materialised scores) or 2 (fused, 16-row waves at every head size)");
-  tribe_internal_attention_set_wide384(mode != 2);
+  TRIBE_REQUIRE(mode >= 0 && mode <= 3, "tribe_attention_set_mode: mode must be 0 (auto), 1 (materialised scores), 2 (fused, 16-row waves at every head size) or 3 (dim_head 384 on the key-split kernel)");
+  tribe_internal_attention_set_wide384(mode == 2 ? 0 : (mode == 3 ? 2 : 1));
   g_attn_mode = mode == 1 ? 1 : 0;
   return 0;
 }

@@ -44,4 +44,6 @@ for k in sorted(set(fetch) | set(write)):
 # the per-launch figures only mean something for the batch they were collected at: usage
 #   python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <B per GPU of that run>
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else None
-json.dump({k: v["hbm_bytes"] for k, v in out.items()} | {"_sequences_per_gpu": batch, "_detail": out}, open("profiles/roofline_traffic.json", "w"), indent=1)
+source = sys.argv[4] if len(sys.argv) > 4 else "profiles/*_pmc_traffic.txt"
+json.dump({k: v["hbm_bytes"] for k, v in out.items()} | {"_sequences_per_gpu": batch, "_source": source, "_detail": out},
+          open("profiles/roofline_traffic.json", "w"), indent=1)

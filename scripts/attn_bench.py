@@ -18,7 +18,7 @@ qkv = torch.randn(B * T, 3 * H * D, generator=g, device="cuda").bfloat16()
 flop = 4.0 * T * H * D * B * T
 out = {"B": B, "T": T, "heads": H, "dim_head": D, "gflop": flop / 1e9, "modes": {}}
 ref = None
-for mode, name in ((2, "16-row waves (round 1)"), (0, "32-row waves, one per SIMD")):
+for mode, name in ((2, "16-row waves (round 1)"), (0, "32-row waves, one per SIMD"), (3, "key-split pairs, two per SIMD")):
     ops.attention_set_mode(mode)
     for _ in range(3):
         y = ops.attention(qkv, B, T, H, D, D**-0.5)

@@ -222,9 +222,10 @@ def test_rotary(ops, interleaved):
 
 
 # 0 = fused flash-style kernels (dim_head 384: 32 query rows per wave, one wave per SIMD), 1 = materialised scores (3 kernels),
-# 2 = fused with dim_head 384 on the 16-row kernel.  Sequence lengths cover whole tiles, a ragged last tile (70, 298, 33, 1000),
+# 2 = fused with dim_head 384 on the 16-row kernel, 3 = dim_head 384 on the key-split kernel (two waves per SIMD, each half of
+# the head dimension).  Sequence lengths cover whole tiles, a ragged last tile (70, 298, 33, 1000),
 # fewer keys than one tile (7) and the deferred-max rescale late in the key loop (1024).
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("B,T,h,d", [(2, 70, 4, 64), (1, 298, 2, 192), (3, 128, 8, 384), (2, 1024, 2, 384), (1, 33, 1, 128), (2, 70, 3, 384),
                                      (1, 298, 8, 384), (1, 7, 2, 384), (1, 1000, 1, 384)])
 def test_attention(ops, B, T, h, d, mode):
