@@ -30,21 +30,18 @@ constexpr int TRIBE_ROLE_EXT = 100;  // kernel instantiation carrying the extend
 // =============================================================================================
 namespace big {
 constexpr int BM = 256, BN = 256;
-constexpr int A_BYTES = BM * BK * 2;          // 32 KiB: one operand of one K-tile
-// A panels (activations, streamed once per row band) get THREE slots, B panels (weights, re-read by every row band) two:
-// 160 KiB, the whole LDS.  With two slots each a half-tile is restaged the moment its slot frees and waited for one K-tile
-// (~1.7 us) later; leaving only 4 / 2 instead of 8 loads per wave in flight at the steady-state waits cost FF1 +13 % / +28 %
-// (profiles/r02_h_gemm_inflight_experiment.txt): the loop is sensitive to how long its loads may stay in flight.  The third A
-// slot doubles the lead of the A half-tiles to two K-tiles.
-constexpr int A_SLOTS = 3, B_SLOTS = 2;
-constexpr int B_BASE = A_SLOTS * A_BYTES;
-constexpr int SMEM_BYTES = (A_SLOTS + B_SLOTS) * A_BYTES;   // 160 KiB
+constexpr int A_BYTES = BM * BK * 2;          // 32 KiB
+constexpr int BUF_BYTES = 2 * A_BYTES;        // A + B of one K-tile: 64 KiB
+constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // 128 KiB
 }  // namespace big
 
 #define TRIBE_WAIT_VMCNT_(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define TRIBE_WAIT_VMCNT(n) TRIBE_WAIT_VMCNT_(n)
+// Loads a wave leaves in flight at the two steady-state waits.  Experiment (profiles/r02_h_gemm_inflight_experiment.txt): 4 / 2
+// instead of 8 cost FF1 +13 % / +28 % and FF2 +30 % / +34 % -- the loop needs its full K-tile of lead; a THIRD A slot (160 KiB
+// LDS, A half-tiles issued two K-tiles ahead) bought nothing (3.88 vs 3.89 ms), so the two-buffer ring stays.
 #ifndef TRIBE_GEMM_VM_STEADY
-#define TRIBE_GEMM_VM_STEADY 8   // loads a wave leaves in flight at the steady-state waits (experiment: 4 / 2 = fewer bytes in flight)
+#define TRIBE_GEMM_VM_STEADY 8
 #endif
 
 // Diagnostic build only (-DTRIBE_GEMM_STAMPS): s_memtime stamps around the slots of the K loop, summed per wave and
@@ -101,20 +98,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
       a_src[h][j] = A + gr * g.lda + schunk * 8;
       b_src[h][j] = B + gc * g.ldb + schunk * 8;
       a_lds[h][j] = ra * 128;
-      b_lds[h][j] = rb * 128;
+      b_lds[h][j] = A_BYTES + rb * 128;
     }
 
-  // which: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1; K-tile kt lives in A slot kt % 3 and B slot kt % 2
-  auto stage = [&](int which, int kt) {
+  // which: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1
+  auto stage = [&](int which, int buf, int kt) {
+    char* base = smem + buf * BUF_BYTES;
     const int koff = kt * BK;
     if (which == 0 || which == 3) {
       const int h = which == 3;
-      char* base = smem + (kt % A_SLOTS) * A_BYTES;
       __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][0] + koff), (lptr_t)(base + a_lds[h][0]), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][1] + koff), (lptr_t)(base + a_lds[h][1]), 16, 0, 0);
     } else {
       const int h = which == 2;
-      char* base = smem + B_BASE + (kt % B_SLOTS) * A_BYTES;
       __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][0] + koff), (lptr_t)(base + b_lds[h][0]), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][1] + koff), (lptr_t)(base + b_lds[h][1]), 16, 0, 0);
     }
@@ -129,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const int frow = lane & 15, fq = lane >> 4;
   const int coff0 = ((fq ^ (frow & 7)) << 4), coff1 = (((4 + fq) ^ (frow & 7)) << 4);
   const int a_rd = (wr * 128 + frow) * 128;            // + mh*8192 + i*2048 + coff
-  const int b_rd = (wc * 64 + frow) * 128;             // + nh*4096 + j*2048 + coff
+  const int b_rd = A_BYTES + (wc * 64 + frow) * 128;   // + nh*4096 + j*2048 + coff
 
   bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
 
@@ -184,54 +180,47 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0};  // 0 LDS reads, 1 stage + vmcnt wait, 2 barrier 1, 3 MFMA cluster, 4 barrier 2
 #endif
 
-  // ---- prologue, in the issue order of the steady state (the counted waits rely on it): A(0); then what "phase B(-2)" would
-  // have staged: A0(1), B(0); "phase A(-1)": A1(1); "phase B(-1)": A0(2), B(1) ----
-  stage(0, 0); stage(3, 0);
-  if (nk > 1) stage(0, 1);
-  stage(1, 0); stage(2, 0);
-  if (nk > 1) stage(3, 1);
-  if (nk > 2) stage(0, 2);
-  if (nk > 1) { stage(1, 1); stage(2, 1); }
-  // K-tile 0 must have landed; younger than B1(0): A1(1), A0(2), B0(1), B1(1)
-  if (nk > 2) TRIBE_WAIT_VMCNT(8); else if (nk > 1) TRIBE_WAIT_VMCNT(6); else TRIBE_WAIT_VMCNT(0);
+  // ---- prologue: K-tile 0 completely, K-tile 1 minus its last half-tile ----
+  stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
+  if (nk > 1) {
+    stage(0, 1, 1); stage(1, 1, 1); stage(2, 1, 1);
+    TRIBE_WAIT_VMCNT(6);
+  } else {
+    TRIBE_WAIT_VMCNT(0);
+  }
   __builtin_amdgcn_s_barrier();
   // stagger: group wr = 1 runs one barrier behind group wr = 0 for the whole K loop (LDS-read slots of one
   // group overlap MFMA slots of the other); group 0 pays the matching barrier after the loop.
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
-  int aslot = 0;   // t % 3 without a division in the loop
   for (int t = 0; t < nk; ++t) {
-    const char* abase = smem + aslot * A_BYTES;
-    const char* bbase = smem + B_BASE + (t & 1) * A_BYTES;
-    // ---- phase A: quadrants (0,0) and (0,1): 16 fragment reads, 32 MFMAs.  Restage: A half 1 of K-tile t+2 into the A slot
-    // K-tile t-1 used (its half 1 was last read in phase B of K-tile t-1).  Nothing to retire here: A half 1 of THIS K-tile
-    // was issued before the B halves that the previous phase B already waited for.
+    const int cur = t & 1;
+    const char* base = smem + cur * BUF_BYTES;
+    // ---- phase A: quadrants (0,0) and (0,1): 16 fragment reads, 32 MFMAs.  Restage: the last half-tile (A half 1)
+    // of K-tile t+1 into the other buffer (its previous content was last read in phase B of K-tile t-1).
     TRIBE_STAMP(ts0);
-    TRIBE_LDS_B(bbase, 0, fb0)
-    TRIBE_LDS_B(bbase, 1, fb1)
-    TRIBE_LDS_A(abase, 0)
+    TRIBE_LDS_B(base, 0, fb0)
+    TRIBE_LDS_B(base, 1, fb1)
+    TRIBE_LDS_A(base, 0)
     TRIBE_STAMP(ts1);
     TRIBE_STAMP_ACC(0, ts0, ts1);
-    if (t + 2 < nk) stage(3, t + 2);
+    // retire A half 1 of THIS K-tile (read in phase B): behind it in the queue are the three half-tiles of
+    // K-tile t+1 issued in the previous phase B and the one issued just now
+    if (t + 1 < nk) { stage(3, cur ^ 1, t + 1); TRIBE_WAIT_VMCNT(TRIBE_GEMM_VM_STEADY); } else { TRIBE_WAIT_VMCNT(0); }
     TRIBE_PHASE_SYNC_MMA2(0, 0, fb0, 0, 1, fb1)
-    // ---- phase B: quadrants (1,1) and (1,0): 8 fragment reads, 32 MFMAs.  A half 0 of this A slot and both B halves of this
-    // B slot were last read in phase A -> restage them for K-tiles t+3 / t+2, then retire what phase A of K-tile t+1 reads
-    // (A half 0 and both B halves of t+1); younger than those in the queue: A1(t+2) and the three half-tiles just issued.
+    // ---- phase B: quadrants (1,1) and (1,0): 8 fragment reads, 32 MFMAs.  A half 0 and both B halves of THIS
+    // buffer were last read in phase A -> restage them for K-tile t+2.
     TRIBE_STAMP(ts0);
-    TRIBE_LDS_A(abase, 1)
+    TRIBE_LDS_A(base, 1)
     TRIBE_STAMP(ts1);
     TRIBE_STAMP_ACC(0, ts0, ts1);
-    if (t + 3 < nk) {
-      stage(0, t + 3); stage(1, t + 2); stage(2, t + 2);
-      TRIBE_WAIT_VMCNT(TRIBE_GEMM_VM_STEADY);
-    } else if (t + 2 < nk) {
-      stage(1, t + 2); stage(2, t + 2);
-      TRIBE_WAIT_VMCNT(6);   // A1(t+2), B0(t+2), B1(t+2)
+    if (t + 2 < nk) {
+      stage(0, cur, t + 2); stage(1, cur, t + 2); stage(2, cur, t + 2);
+      TRIBE_WAIT_VMCNT(TRIBE_GEMM_VM_STEADY);  // retire A0/B0/B1 of K-tile t+1; behind them: A1(t+1) and the three just issued
     } else if (t + 1 < nk) {
-      TRIBE_WAIT_VMCNT(0);
+      TRIBE_WAIT_VMCNT(2);  // behind them: only A1(t+1)
     }
     TRIBE_PHASE_SYNC_MMA2(1, 1, fb1, 1, 0, fb0)
-    aslot = (aslot == A_SLOTS - 1) ? 0 : aslot + 1;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
 #ifdef TRIBE_GEMM_STAMPS
