@@ -687,22 +687,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wide384_kernel(const AttnArgs
 //     summed, so both waves hold the same full S^T (a + b == b + a in IEEE) and run the same softmax;
 //   * O^T[half c] += V^T[half c] . P^T: 12 MFMAs into 6 accumulator tiles (96 AGPRs); Q^T[half c] sits in 32 more AGPRs (MFMA B
 //     operands may be accumulator registers; 8 of the 12 fragments, a[96:127], the other 4 in VGPRs), 128 VGPRs for the rest.
-// MEASURED (profiles/r02_g_attn_bench.json): 1.14 ms at B = 64, the same as the one-wave kernel (1.13-1.16 ms), and neither an
-// L2 warm-up of the K / V lines four tiles ahead nor buffer-descriptor DMA moved either kernel.  All three structures (16-row
-// 1.28 ms) sit near one line: a workgroup of 128 queries streams 48 KiB of K / V per 32-key tile, the LDS rings leave about one
-// tile (48 KiB) in flight, and at the ~2 us loaded L2 latency of this access pattern that is ~24 GB/s per CU = 2.1 us per tile
-// (the 256^2 GEMM keeps 80 KiB in flight and streams 38 GB/s per CU).  More bytes in flight need LDS that a DH = 384 tile does
-// not leave (160 KiB - 48 KiB working set); this kernel is kept as the selectable variant (tribe_attention_set_mode(3)).
-// Same LDS image, operand maps and AGPR ownership rules as the kernel above.  K ring 2 slots, V ring 3 slots, exchange buffer
-// 32 KiB: 152 KiB.  One barrier per tile, between the partial S^T and the softmax (it publishes the partials AND tile t + 1).
+// MEASURED (profiles/r02_g_attn_bench.json): 1.14-1.22 ms at B = 64 across three ring designs, the same as the
+// one-wave kernel (1.13-1.17 ms).  With every MFMA and fragment read compiled out (-DTRIBE_ATTN_DMA_ONLY) it runs 0.83 ms: the
+// K / V stream of a 128-query workgroup (48 KiB per 32-key tile, ~30 GB/s per CU) is the floor, and the matrix work adds its
+// 0.3 ms on top of it instead of under it.  Kept as the selectable variant (tribe_attention_set_mode(3)).
+// Same LDS image, operand maps and AGPR ownership rules as the kernel above.  Unified K / V ring of 5 slots + exchange buffer
+// 32 KiB: 152 KiB.  Two barriers per tile: after the partial S^T (publishes the partials and the half-tiles waited for) and after P V.
 struct KSplitCfg {
   static constexpr int DH = 384, ROWB = 768, KV = 32, CHUNKS = 48;
   static constexpr int KS = 12, NT = 6, Q_AGPR = 8;    // k-steps of 16 and 32-row O^T tiles PER WAVE; Q^T fragments kept in AGPRs
   static constexpr int TILE_BYTES = KV * ROWB;
-  static constexpr int WAVES = 8, PPW = 3;             // 24 pieces per K or V tile, 3 per wave
-  static constexpr int K_SLOTS = 2, V_SLOTS = 3;
-  static constexpr int V_BASE = K_SLOTS * TILE_BYTES;
-  static constexpr int X_BASE = (K_SLOTS + V_SLOTS) * TILE_BYTES;   // exchange buffer: 8 waves x 4 KiB
+  static constexpr int WAVES = 8, PPW = 6;             // 24 pieces per K or V half-tile, 6 per wave of the half that moves it
+  static constexpr int SLOTS = 5;                      // unified K / V ring (see the kernel)
+  static constexpr int X_BASE = SLOTS * TILE_BYTES;    // exchange buffer: 8 waves x 4 KiB
   static constexpr int SMEM = X_BASE + WAVES * 4096;   // 152 KiB
   static constexpr int DEPTH = 4;
 };
@@ -743,16 +740,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ksplit384_kernel(const AttnAr
   static_for<0, C::NT>([&](auto n) { AccTile<decltype(n)::value>::zero(); });
   asm volatile("s_nop 7" ::: "memory");   // v_accvgpr_write -> MFMA operand
 
-  // ---- staging plan: piece i of this wave covers linear 16-byte chunks [(wave + 8 i) * 64, +64) of a tile ----
+  // ---- staging plan.  The waves of half c = 0 move ALL K half-tiles, those of c = 1 all V half-tiles, 6 pieces of 1 KiB per wave
+  // (piece = qj + 4 i): the two waves of a SIMD (same qj, c = 0 / 1) then never issue LDS-DMA in the same phase -- K pieces go out
+  // during S^T phases, V pieces during P V phases -- so one wave's ~100-cycle LDS-DMA issues overlap the other's MFMAs instead of
+  // colliding with its own partner's (both waves run the same code in lockstep; with pieces split evenly the kernel ran
+  // 0.83 ms WITHOUT any MFMA and 1.16 ms with them). ----
   int st_off[C::PPW];
 #pragma unroll
   for (int i = 0; i < C::PPW; ++i) {
-    const int p = (wave + C::WAVES * i) * 64 + lane;
+    const int p = (qj + 4 * i) * 64 + lane;
     st_off[i] = (p / C::CHUNKS) * (int)ld + swz_wide(p % C::CHUNKS, p / C::CHUNKS) * 8;
   }
-  auto stage_piece = [&](int which, int slot_i, int key0, int i) {
-    const unsigned short* src = (which ? vbase : kbase) + (int64_t)key0 * ld;
-    const int piece = wave + C::WAVES * i;
+  const unsigned short* my_base = c ? vbase : kbase;
+  auto stage_piece = [&](int slot_i, int key0, int i) {
+    const unsigned short* src = my_base + (int64_t)key0 * ld;
+    const int piece = qj + 4 * i;
     int off = st_off[i];
     if (key0 + C::KV > T) {   // tail keys re-read the last valid row; they are masked to -inf in the softmax
       const int p = piece * 64 + lane;
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ksplit384_kernel(const AttnAr
       const int row = (key0 + row0 < T) ? row0 : T - 1 - key0;
       off = row * (int)ld + swz_wide(p % C::CHUNKS, row0) * 8;
     }
-    glds16(src + off, lds_addr(smem) + (which ? C::V_BASE : 0) + slot_i * C::TILE_BYTES + piece * 1024);
+    glds16(src + off, lds_addr(smem) + slot_i * C::TILE_BYTES + piece * 1024);
   };
 
   // ---- per-lane LDS read offsets: K row reads (4 registers: chunk = 16 s + 8 c + 2 i + h) and V transposed reads (4 registers:
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ksplit384_kernel(const AttnAr
 #pragma unroll
     for (int lh = 0; lh < 2; ++lh) {
       const int row = 4 * h + tq + 8 * lh;
-      va[e][lh] = C::V_BASE + row * C::ROWB + swz_wide(4 * (2 * c + e) + 2 * g1 + (tp >> 1), row) * 16 + (tp & 1) * 8;
+      va[e][lh] = C::TILE_BYTES + row * C::ROWB + swz_wide(4 * (2 * c + e) + 2 * g1 + (tp >> 1), row) * 16 + (tp & 1) * 8;
     }
   auto ld_k = [&](int k) -> bf16x8_t { return *(const bf16x8_t*)(smem + ka[k & 3] + (k >> 2) * 256); };
   auto ld_v = [&](int i) -> bf16x8_t {   // fragment i = 6 s_key + n, tile n = 2 u + e
@@ -792,14 +794,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ksplit384_kernel(const AttnAr
 
   float m_run = -INFINITY, l_run = 0.f;
   const int ntiles = (T + C::KV - 1) / C::KV;
+  // ---- unified ring of five 24-KiB slots: half-tile hh (even: K(hh / 2), odd: V(hh / 2)) lives in slot hh % 5 and is consumed in
+  // phase hh (S^T of tile t = phase 2 t, P V = phase 2 t + 1).  Two barriers per tile: B1 after the partial S^T (publishes the
+  // partials, frees K(t)'s slot), B2 after P V (frees V(t)'s slot); a freed slot is refilled at once with the half-tile five
+  // ahead -- V(t + 2) after B1(t), K(t + 3) after B2(t) -- and waited for just before the B1 that precedes its first read, three
+  // to four phases later.  (With one barrier per tile either K or V had ~1.2 phases between issue and wait, less than the loaded
+  // L2 latency, and the wait showed up in every tile.) ----
+  auto stage_half = [&](int hh) {   // the six pieces this wave owns of half-tile hh (K half-tiles: c = 0 waves, V: c = 1)
+    if ((hh & 1) != c) return;
 #pragma unroll
-  for (int i = 0; i < C::PPW; ++i) { stage_piece(0, 0, 0, i); stage_piece(1, 0, 0, i); }
-  if (ntiles > 1) {
-#pragma unroll
-    for (int i = 0; i < C::PPW; ++i) { stage_piece(0, 1, C::KV, i); stage_piece(1, 1, C::KV, i); }
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 0; i < C::PPW; ++i) stage_piece(hh % C::SLOTS, (hh >> 1) * C::KV, i);
+  };
+  const int nhalf = 2 * ntiles;
+  for (int hh = 0; hh < C::SLOTS && hh < nhalf; ++hh) stage_half(hh);            // K0 V0 K1 V1 K2
+  // K(0) must have landed: a c = 0 wave has K(1), K(2) behind it in its queue (V waves wait for nothing here: V(0) is waited
+  // for before the first B1)
+  if (c == 0) {
+    if (ntiles >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (ntiles == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
 
@@ -807,26 +820,38 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ksplit384_kernel(const AttnAr
 #pragma unroll
   for (int d = 0; d < C::DEPTH; ++d) kf[d] = ld_k(d);
 
-  int vcur = 0;
+  int kslot = 0, vslot = 1;   // ring slots of K(t) and V(t)
   for (int t = 0; t < ntiles; ++t) {
     // ---- partial S^T over this wave's half of the head dimension ----
     f32x16_t s;
     static_for<0, C::KS>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
+#ifndef TRIBE_ATTN_DMA_ONLY
       if constexpr (k + C::DEPTH < C::KS) kf[k + C::DEPTH] = ld_k(k + C::DEPTH);
-      else vf[k + C::DEPTH - C::KS] = ld_v(k + C::DEPTH - C::KS);
+#endif
+      // K(t + 2) into the slot V(t - 1) left (B2 of the previous tile freed it): the K waves, one piece every second MFMA
+      if constexpr (k % 2 == 1) { if (c == 0 && t >= 1 && t + 2 < ntiles) stage_piece((2 * t + 4) % C::SLOTS, (t + 2) * C::KV, k / 2); }
       __builtin_amdgcn_sched_barrier(0);
+#ifndef TRIBE_ATTN_DMA_ONLY
       if constexpr (k == 0) QFrag<k>::mfma_first(s, kf[k]);
       else if constexpr (k < C::Q_AGPR) QFrag<k>::mfma(s, kf[k]);
       else mfma_s(s, kf[k], qv[k - C::Q_AGPR]);
+#else
+      if constexpr (k == 0) { for (int r = 0; r < 16; ++r) s[r] = (float)r31; }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_nop 11" : "+v"(s));
     // ---- hand the partial to the partner wave (the other half of the head dimension, same query block) ----
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) *(f32x4_t*)(smem + x_mine + q4 * 1024) = f32x4_t{s[4 * q4], s[4 * q4 + 1], s[4 * q4 + 2], s[4 * q4 + 3]};
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my K(t + 1) / V(t + 1) pieces and my partial have landed
-    __builtin_amdgcn_s_barrier();
+    // V(t) and K(t + 1) must have landed (first read after this barrier).  A K wave has K(t + 2) behind K(t + 1) in its queue (when
+    // it exists), a V wave V(t + 1) behind V(t)
+    if (c == 0 ? (t + 2 < ntiles) : (t + 1 < ntiles)) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // B1(t)
+#pragma unroll
+    for (int d = 0; d < C::DEPTH; ++d) vf[d] = ld_v(d);            // the first V fragments fly under the softmax
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const f32x4_t o4 = *(const f32x4_t*)(smem + x_peer + q4 * 1024);
@@ -866,34 +891,40 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ksplit384_kernel(const AttnAr
     }
     l_run += psum;
 
-    const bool more = t + 2 < ntiles;
-    const int kslot = t & 1;                                    // K(t + 2) replaces K(t); K(t + 1) sits in the other slot
-    const int vnext2 = vcur == 0 ? 2 : vcur - 1;                // (vcur + 2) % 3: the slot V(t - 1) left
-    const int kstep = kslot ? -C::TILE_BYTES : C::TILE_BYTES;
+    // K read addresses move on to K(t + 1)'s slot
+    const int knext = kslot + 2 >= C::SLOTS ? kslot + 2 - C::SLOTS : kslot + 2;
+    const int kstep = (knext - kslot) * C::TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(ka[i]) : "s"(kstep));
     asm volatile("s_nop 1" : "+v"(pf[0]), "+v"(pf[1]));
 
-    // ---- O^T[half c] += V^T[half c] . P^T; this wave's 6 LDS-DMA pieces of tile t + 2 and the first K fragments of tile t + 1
-    // ride along (the partner wave's MFMAs cover their issue time) ----
+    // ---- O^T[half c] += V^T[half c] . P^T; V(t + 2) goes into the slot K(t) left (the partner wave's MFMAs cover the issue
+    // time of the pieces), the first K fragments of tile t + 1 ride under the last MFMAs ----
     static_for<0, 2 * C::NT>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
+#ifndef TRIBE_ATTN_DMA_ONLY
       if constexpr (i + C::DEPTH < 2 * C::NT) vf[i + C::DEPTH] = ld_v(i + C::DEPTH);
       else kf[i + C::DEPTH - 2 * C::NT] = ld_k(i + C::DEPTH - 2 * C::NT);
-      if constexpr (i % 2 == 1 && i / 2 < 2 * C::PPW) {
-        if (more) stage_piece((i / 2) & 1, (i / 2) & 1 ? vnext2 : kslot, (t + 2) * C::KV, i / 4);
-      }
+#endif
+      if constexpr (i % 2 == 1) { if (c == 1 && t + 2 < ntiles) stage_piece(kslot, (t + 2) * C::KV, i / 2); }
       __builtin_amdgcn_sched_barrier(0);
+#ifndef TRIBE_ATTN_DMA_ONLY
       AccTile<i % C::NT>::mfma(vf[i], pf[i / C::NT]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     });
-    const int vstep = (vcur == C::V_SLOTS - 1) ? -(C::V_SLOTS - 1) * C::TILE_BYTES : C::TILE_BYTES;
+    const int vnext = vslot + 2 >= C::SLOTS ? vslot + 2 - C::SLOTS : vslot + 2;
+    const int vstep = (vnext - vslot) * C::TILE_BYTES;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       asm volatile("v_add_u32 %0, %1, %0" : "+v"(va[e][0]) : "s"(vstep));
       asm volatile("v_add_u32 %0, %1, %0" : "+v"(va[e][1]) : "s"(vstep));
     }
-    vcur = (vcur == C::V_SLOTS - 1) ? 0 : vcur + 1;
+    kslot = knext;
+    vslot = vnext;
+    // B2(t): every wave is done with V(t) -- its slot takes K(t + 3) during the next S^T phase.  The V fragment reads were consumed
+    // by the MFMAs above; the K(t + 1) prefetch reads may stay in flight across the barrier.
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- normalise and write this wave's half: tile n = 2 u + e holds d = 32 (4 u + 2 c + e) + (r & 3) + 8 (r >> 2) + 4 h ----

@@ -185,3 +185,39 @@ def test_get_data_runs_the_hip_extractors_and_matches_the_cpu_route(tmp_path):
             states = vhf(pixel_values_videos=pix, output_hidden_states=True, skip_predictor=True).hidden_states
         want_v = torch.stack([s[0].mean(0) for s in states]).numpy()                                          # video.py:225-228
         assert _rel(lat_v[:, :, k], want_v) < 3e-2, k
+
+
+def test_plugins_share_one_store_with_the_batch_loader(g11):
+    """INTEGRATION.md section D: the three plugins bound to ONE HbmFeatureStore under the SegmentData keys fill it in `prepare`;
+    `GpuSegmentLoader.batch` then writes the projector operands directly -- equal to bf16(plugin __call__ tensor) per segment."""
+    from data_utils.events import Sound, Video, Word
+    from data_utils.features.audio import Wav2VecBert
+    from data_utils.features.text import LLAMA3p2
+    from data_utils.features.video import VJEPA2
+    from data_utils.gpu_loader import GpuSegmentLoader, HbmFeatureStore
+    from data_utils.segments import Segment
+
+    snd = [Sound(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"a{e}.wav", timeline="t") for e in range(2)]
+    vid = [Video(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"v{e}.mkv", timeline="t") for e in range(2)]
+    words = [Word(start=float(s), duration=float(d), text=f"w{i}", context=f"c{i}", timeline="t")
+             for i, (s, d) in enumerate(zip(g11["word_start"], g11["word_dur"]))]
+    text, audio, video = LLAMA3p2(device="cuda"), Wav2VecBert(device="cuda"), VJEPA2(device="cuda")
+    for e in range(2):
+        audio._ram[audio._item_uid(snd[e])] = g11[f"dense_states{e}"]
+        video._ram[video._item_uid(vid[e])] = g11[f"dense_states{e}"]
+    for i, w in enumerate(words):
+        text._ram[text._item_uid(w)] = g11["word_states"][i]
+    store = HbmFeatureStore([])
+    events = words + snd + vid
+    for key, f in (("text", text), ("audio", audio), ("video", video)):
+        f.bind(store, name=key)
+        f.prepare(events)
+    loader = GpuSegmentLoader(store)
+    segs = [Segment(start=s0, duration=12.0, ns_events=list(events)) for s0 in (3.0, 10.25, 20.0)]
+    batch = loader.batch(segs)
+    assert set(batch.data) == {"text", "audio", "video"}
+    for key, f in (("text", text), ("audio", audio), ("video", video)):
+        got = batch.data[key].unpack()
+        for b, seg in enumerate(segs):
+            want = f(seg.ns_events, start=seg.start, duration=seg.duration)
+            assert torch.equal(got[b], want.bfloat16().float().reshape(got[b].shape)), (key, b)
