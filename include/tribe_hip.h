@@ -102,7 +102,11 @@ int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partia
 
 /* Measurement hook (bench.py): while enabled, every GEMM launch is bracketed by HIP events on ITS
  * stream.  tribe_prof_end synchronises them and returns, per role, the summed kernel time (ms), the
- * launch count and the summed algorithmic FLOPs (2*M*N*K*batches).  Host arrays of >= TRIBE_ROLE_COUNT. */
+ * launch count and the summed algorithmic FLOPs (2*M*N*K*batches).  Host arrays of >= TRIBE_ROLE_COUNT.
+ * PROCESS-WIDE state (one mutex-guarded record list): the compute entry points are re-entrant and keep no state, but this
+ * diagnostic pair, tribe_attention_set_mode and the one-time hipFuncSetAttribute flags of the kernels are per process, not
+ * per device or per thread -- in line with the deployment model (one process per GPU, main.py:388-395).  Call begin / end
+ * from the thread that launches. */
 int tribe_prof_begin(int32_t max_records);
 int tribe_prof_end(int32_t n_roles, double* total_ms_host, int64_t* count_host, double* flops_host);
 
