@@ -16,22 +16,32 @@ with tempfile.TemporaryDirectory() as tmp:
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-I{CSRC}", "-save-temps", "-c",
                     str(CSRC / "attention.hip"), "-o", f"{tmp}/attn.o"], check=True, cwd=tmp, capture_output=True)
     text = Path(tmp, "attention-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
-m = re.search(r"^(_ZN\S*attn_fwd_wide384\S*):.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
-body = m.group(2)
-meta = {k: int(v) for k, v in re.findall(r"\.amdhsa_(next_free_vgpr|accum_offset|private_segment_fixed_size)\s+(\d+)", body)}
-in_asm, bad, mix = False, [], {"mfma": 0, "ds_read": 0, "global_load_lds": 0, "s_barrier": 0, "v_exp": 0}
-for ln in body.splitlines():
-    if "#ASMSTART" in ln:
-        in_asm = True
-    elif "#ASMEND" in ln:
-        in_asm = False
-    for k in mix:
-        if re.search(rf"\b{k}", ln):
-            mix[k] += 1
-    if not in_asm and re.search(r"\bv_accvgpr|\bv_mfma|scratch_", ln):
-        bad.append(ln.strip())
-print("registers:", meta, " instruction mix (whole kernel):", mix)
-if meta.get("private_segment_fixed_size", 1) or bad:
-    print("FAIL: compiler touched accumulator registers / scratch outside the asm blocks:", *bad[:10], sep="\n  ")
+def audit(kernel: str, max_regs: int) -> bool:
+    m = re.search(rf"^(_ZN\S*{kernel}\S*):.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+    if m is None:
+        print(f"FAIL: kernel {kernel} not found in the ISA")
+        return False
+    body = m.group(2)
+    meta = {k: int(v) for k, v in re.findall(r"\.amdhsa_(next_free_vgpr|accum_offset|private_segment_fixed_size)\s+(\d+)", body)}
+    in_asm, bad, mix = False, [], {"v_mfma": 0, "ds_read": 0, "global_load_lds": 0, "s_barrier": 0, "v_exp": 0}
+    for ln in body.splitlines():
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
+        for k in mix:
+            if re.search(rf"\b{k}", ln):
+                mix[k] += 1
+        if not in_asm and re.search(r"\bv_accvgpr|\bv_mfma|scratch_", ln):
+            bad.append(ln.strip())
+    print(f"{kernel}: registers {meta}; instruction mix (whole kernel) {mix}")
+    if meta.get("private_segment_fixed_size", 1) or bad or meta.get("next_free_vgpr", 9999) > max_regs:
+        print("FAIL: scratch, too many registers, or compiler traffic on accumulator registers outside the asm blocks:", *bad[:10], sep="\n  ")
+        return False
+    return True
+
+
+ok = audit("attn_fwd_wide384", 512) & audit("attn_fwd_ksplit384", 256)
+if not ok:
     sys.exit(1)
 print("OK: no scratch, no compiler accumulator-register traffic")

@@ -152,3 +152,26 @@ def test_layer_grouping_matches_oracle():
             np.testing.assert_allclose(aggregate_layers(lat, layers, agg), tribe_ref.aggregate_layers(lat, layers, agg))
     with pytest.raises(ValueError):
         aggregate_layers(lat, [0.5, 1.0], "bogus")
+
+
+def test_attention_kernels_own_their_accumulator_registers():
+    """The DH = 384 attention kernels keep O^T (and part of Q^T) in LITERAL accumulator registers written by inline asm
+    (csrc/attn_acc_regs.h).  That is only sound while the compiler allocates nothing of its own there: the audit recompiles
+    attention.hip and requires no scratch and no compiler-generated v_accvgpr_* / MFMA outside the asm blocks, within the
+    register budget of one (512) / two (256) waves per SIMD.  Needs hipcc (present in the build container and on the GPU box)."""
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import pytest
+
+    if not Path("/opt/rocm/bin/hipcc").exists() and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "scripts" / "check_attn_wide_isa.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    # the generated header is in step with its generator
+    before = (root / "algonauts-2025_amd" / "csrc" / "attn_acc_regs.h").read_text()
+    subprocess.run([sys.executable, str(root / "scripts" / "gen_attn_acc_regs.py")], check=True, capture_output=True)
+    assert (root / "algonauts-2025_amd" / "csrc" / "attn_acc_regs.h").read_text() == before
