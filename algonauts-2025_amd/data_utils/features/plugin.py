@@ -48,6 +48,8 @@ class HbmFeaturePlugin(pydantic.BaseModel):
     _KIND: tp.ClassVar[str] = "sampled"                 # "sampled": [n_states, D, T_event] at 2 Hz; "words": [n_states, D] held for the word
     _PASS_EVENT_DURATION: tp.ClassVar[bool] = False     # video.py:176-182 validates against event.duration, audio.py:241 does not
     _FREQUENCY: tp.ClassVar[float] = 2.0
+    _START_SHIFT: tp.ClassVar[float] = 0.0              # neuro.py:150: the recording sits 4.47 s before its event
+    _FIRST_EVENT_ONLY: tp.ClassVar[bool] = False        # neuro.py:81: events[:1]
 
     _event_types_helper: tp.Any = pydantic.PrivateAttr(default=None)
     _missing_default: torch.Tensor | None = pydantic.PrivateAttr(default=None)
@@ -93,9 +95,18 @@ class HbmFeaturePlugin(pydantic.BaseModel):
     @property
     def spec(self) -> FeatureSpec:
         if self._spec is None:
-            self._spec = FeatureSpec(self.name, self._KIND, self._EVENT_TYPE, frequency=self._FREQUENCY, layers=tuple(self.layers),  # type: ignore[attr-defined]
-                                     layer_aggregation=self.layer_aggregation, pass_event_duration=self._PASS_EVENT_DURATION)
+            self._spec = self._make_spec(self.name)  # type: ignore[attr-defined]
         return self._spec
+
+    def _make_spec(self, key: str) -> FeatureSpec:
+        return FeatureSpec(key, self._KIND, self._EVENT_TYPE, frequency=self._FREQUENCY, layers=tuple(self.layers),
+                           layer_aggregation=self.layer_aggregation, pass_event_duration=self._PASS_EVENT_DURATION,
+                           start_shift=self._START_SHIFT, first_event_only=self._FIRST_EVENT_ONLY)
+
+    @property
+    def frequency(self) -> float:
+        """Output grid in Hz (dataloader.py:69-87 reads it to turn `pad_duration` into a length)."""
+        return self._FREQUENCY
 
     @property
     def store(self) -> HbmFeatureStore:
@@ -109,8 +120,7 @@ class HbmFeaturePlugin(pydantic.BaseModel):
         (default: the spec already registered under this plugin's `name`, else it is added)."""
         key = name or self.spec.name
         if key != self.spec.name:
-            self._spec = FeatureSpec(key, self._KIND, self._EVENT_TYPE, frequency=self._FREQUENCY, layers=tuple(self.layers),
-                                     layer_aggregation=self.layer_aggregation, pass_event_duration=self._PASS_EVENT_DURATION)
+            self._spec = self._make_spec(key)
         store.specs.setdefault(key, self.spec)
         self._spec = store.specs[key]
         self._store, self._loader = store, GpuSegmentLoader(store)
@@ -193,12 +203,14 @@ class HbmFeaturePlugin(pydantic.BaseModel):
             return default.unsqueeze(-1).repeat([1 for _ in range(default.ndim)] + [n_times])
         if not events:   # text.py:108-117 with nothing to add: the empty accumulator, shape (0, T)
             return torch.zeros(0, max(1, freq.to_ind(duration)), device="cuda" if self.device == "cuda" else "cpu")
+        if self._FIRST_EVENT_ONLY:
+            events = events[:1]
         self._ensure_resident(events)
         window = types.SimpleNamespace(ns_events=events, start=start, duration=duration)
         flat = self._loader.feature(self.spec, [window], exact=True)[0]                    # f32 [L*D, T] on the GPU
         self._loader.clear_plans()
         L, D = self.store.channels[self.spec.name]
-        squeeze = self.layer_aggregation is not None and len(layer_indices(self._n_states or 2, self.layers)) == 1
+        squeeze = self._KIND == "target" or (self.layer_aggregation is not None and len(layer_indices(self._n_states or 2, self.layers)) == 1)
         tensor = flat.view(D, -1) if squeeze else flat.view(L, D, -1)
         if self._missing_default is None:
             self._missing_default = torch.zeros(*tensor.shape[:-1], dtype=tensor.dtype, device=tensor.device)

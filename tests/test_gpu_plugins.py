@@ -221,3 +221,61 @@ def test_plugins_share_one_store_with_the_batch_loader(g11):
         for b, seg in enumerate(segs):
             want = f(seg.ns_events, start=seg.start, duration=seg.duration)
             assert torch.equal(got[b], want.bfloat16().float().reshape(got[b].shape)), (key, b)
+
+
+def test_segment_dataset_with_all_five_features(g11):
+    """The reference's SegmentDataset (dataloader.py:111-187) over this build's plugins: text / audio / video / Fmri / SubjectEncoder
+    items (`__getitem__` = feature(events, start, duration, trigger) + pad + batch axis), collated, against the G11 tensors; and the
+    batched fast path (`gpu_batches`) against the collated items."""
+    from data_utils.dataloader import SegmentDataset
+    from data_utils.events import Fmri as FmriEvent
+    from data_utils.events import Sound, Video, Word
+    from data_utils.features.audio import Wav2VecBert
+    from data_utils.features.neuro import Fmri
+    from data_utils.features.subject import SubjectEncoder
+    from data_utils.features.text import LLAMA3p2
+    from data_utils.features.video import VJEPA2
+    from data_utils.gpu_loader import HbmFeatureStore
+    from data_utils.segments import Segment
+
+    snd = [Sound(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"a{e}.wav", timeline="t") for e in range(2)]
+    vid = [Video(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"v{e}.mkv", timeline="t") for e in range(2)]
+    words = [Word(start=float(s), duration=float(d), text=f"w{i}", context=f"c{i}", timeline="t")
+             for i, (s, d) in enumerate(zip(g11["word_start"], g11["word_dur"]))]
+    rec = FmriEvent(start=float(g11["fmri_start"]), duration=g11["fmri_data"].shape[1] * 1.49, filepath="sub-02.h5", frequency=1 / 1.49, subject="sub-02", timeline="t")
+    other = FmriEvent(start=0.0, duration=10.0, filepath="sub-01.h5", frequency=1 / 1.49, subject="sub-01", timeline="u")
+    feats = {"text": LLAMA3p2(device="cuda"), "audio": Wav2VecBert(device="cuda"), "video": VJEPA2(device="cuda"), "fmri": Fmri(device="cuda"),
+             "subject_id": SubjectEncoder()}
+    for e in range(2):
+        feats["audio"]._ram[feats["audio"]._item_uid(snd[e])] = g11[f"dense_states{e}"]
+        feats["video"]._ram[feats["video"]._item_uid(vid[e])] = g11[f"dense_states{e}"]
+    for i, w in enumerate(words):
+        feats["text"]._ram[feats["text"]._item_uid(w)] = g11["word_states"][i]
+    feats["fmri"]._ram[feats["fmri"]._item_uid(rec)] = g11["fmri_data"]
+    store = HbmFeatureStore([])
+    events = [rec] + words + snd + vid
+    for key, f in feats.items():
+        if key != "subject_id":
+            f.bind(store, name=key)
+        f.prepare(events + [other] if key == "subject_id" else events)
+    assert feats["subject_id"].subject_index == {"sub-01": 0, "sub-02": 1}
+
+    # fMRI items reproduce the reference tensors of G11 (one window each; the recording sits 4.47 s before its event)
+    for si, (s0, sd) in enumerate(zip(g11["fmri_seg_start"], g11["fmri_seg_dur"])):
+        got = feats["fmri"]([rec], start=float(s0), duration=float(sd))
+        assert np.array_equal(got.cpu().numpy(), g11[f"fmri_seg{si}"]), si
+
+    segs = [Segment(start=s0, duration=14.9, ns_events=list(events), _trigger=s0) for s0 in (3.0, 10.25, 20.0, 29.8)]
+    ds = SegmentDataset(feats, segs, pad_duration=14.9)
+    item = ds[1]
+    assert item.data["text"].shape[0] == 1 and item.data["text"].shape[-1] == 30 and item.data["fmri"].shape == (1, g11["fmri_data"].shape[0], 10)
+    assert item.data["subject_id"].tolist() == [[1]]
+    batch = ds.as_one_batch()
+    assert batch.data["audio"].shape[0] == 4 and len(batch.segments) == 4 and batch.data["subject_id"].tolist() == [[1]] * 4
+    fast = list(ds.gpu_batches(batch_size=4))[0]
+    for key in ("text", "audio", "video"):
+        assert torch.equal(fast.data[key].unpack(), batch.data[key].bfloat16().float().reshape(fast.data[key].shape)), key
+    assert torch.equal(fast.data["fmri"], batch.data["fmri"]) and torch.equal(fast.data["subject_id"].cpu(), batch.data["subject_id"].cpu())
+    with pytest.warns(UserWarning, match="cropping"):
+        short = SegmentDataset({"audio": feats["audio"]}, segs, pad_duration=5.0)[0]
+    assert short.data["audio"].shape[-1] == 10
