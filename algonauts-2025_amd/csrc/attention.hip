@@ -22,36 +22,11 @@
 // the row reads of K and the transposed reads of V bank-conflict free.
 // Roofline: MFMA (4*T*DH flop per query row and head); every MFMA streams a 1 KiB operand from LDS, so
 // the LDS read rate (256 B/clk/CU) is the co-bound.
-#include "gemm_common.h"
+#include "attn_common.h"
 #include "attn_acc_regs.h"
-#include <utility>
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-
-// max(a, b, c) in one instruction.  fmaxf() chains compile to v_max_f32 PLUS a canonicalising v_max_f32 x, x per MFMA-produced input
-// (IEEE maxnum semantics): 56 instructions per 128-key tile at DH = 64 where 16 suffice.  Not volatile: the scheduler may move it.
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-
-// One LDS-DMA wave-instruction: lane l copies the 16 bytes at gsrc (per lane) to LDS byte address lds_dst + 16 l (lds_dst
-// wave-uniform).  Inline asm, NOT __builtin_amdgcn_global_load_lds: hipcc tracks the builtin as a VMEM write to LDS and, unable
-// to prove that a later ds_read touches another ring slot, puts s_waitcnt vmcnt(0) in front of the first LDS read after it --
-// every tile then drained ALL its LDS-DMA loads, the multi-slot rings of these kernels never had a tile in flight and each
-// tile paid a full L2 / HBM round trip (seen in the ISA of the round-1 kernels, and in stamps as 5900 of 7600 cycles per tile
-// when pieces were issued between MFMAs).  Unseen by the compiler, the loads are waited for by the kernels' own counted
-// s_waitcnt vmcnt(N) + barrier; hipcc's counted waits for its OWN loads stay correct (hidden younger loads only make a counted
-// wait cover more).  M0 is compiler-reserved: saved and restored inside the statement (guide 5.7).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lptr_t)p; }
 // keys per staged tile = 32 * NSUB: small heads take several 32-key sub-tiles per barrier / softmax pass so that the
 // fixed per-tile cost (barrier, max exchange, rescale test) is amortised over the same number of MFMAs as at DH = 384
 template <int DH>
@@ -82,17 +57,6 @@ __device__ __forceinline__ int swz_chunk(int chunk, int row) {
   return (chunk & ~MASK) | ((chunk ^ ((row & 7) << 1)) & MASK);
 }
 
-struct AttnArgs {
-  const unsigned short* q; const unsigned short* k; const unsigned short* v;
-  unsigned short* out;
-  int64_t ld_q, ld_kv, ld_out;
-  int T, heads_q, group;  // group = heads_q / heads_kv
-  float scale_log2e;
-  int qblocks;
-  int n_bh;   // batch * heads_q: the (sequence, head) pairs
-  // relative_key position bias (Wav2Vec2BertSelfAttention, modeling_wav2vec2_bert.py:308-320): score += q . E[clamp(j - i)]
-  const float* qe; int64_t ld_qe; int qe_stride_h; int rel_left, rel_right;  // qe[row][h * stride + clamp(j-i, -left, right) + left]
-};
 
 // CAUSAL: key <= query (HF LlamaAttention.is_causal, modeling_llama.py); a wave skips key tiles that lie entirely
 // above its 16 query rows, the workgroup stops at the last tile its 128 rows can see.
@@ -408,14 +372,6 @@ __device__ __forceinline__ int swz_wide(int chunk, int row) {
   return (chunk & ~15) | ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) & 15);
 }
 
-// compile-time loop: the accumulator tile index selects literal registers (attn_acc_regs.h)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // S^T accumulation in VGPRs (asm, so that the compiler never allocates an accumulator register of its own: a0..a191 belong to
 // O^T).  hipcc does not know these are MFMAs: the caller pads the result -> VALU hazard (s_nop after the last one).
@@ -426,25 +382,6 @@ __device__ __forceinline__ void mfma_s(f32x16_t& acc, const bf16x8_t& a, const b
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-// The value lane ^ 32 holds, combined with this lane's.  v_permlane32_swap exchanges lanes 32..63 of its first operand with
-// lanes 0..31 of its second: fed two COPIES of x it leaves x[lane & 31] in one register and x[32 + (lane & 31)] in the other, in
-// every lane.  Inline asm with two read-write operands: the builtin handed both copies the same register (the swap then only
-// rotates x by 32 lanes and a lane never sees its own value).  The s_nop pads the VALU-write -> permlane-read hazard.
-__device__ __forceinline__ void pair_split(float x, float& lo, float& hi) {
-  lo = x;
-  hi = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-}
-__device__ __forceinline__ float pair_max(float x) {
-  float lo, hi;
-  pair_split(x, lo, hi);
-  return fmaxf(lo, hi);
-}
-__device__ __forceinline__ float pair_sum(float x) {
-  float lo, hi;
-  pair_split(x, lo, hi);
-  return lo + hi;
-}
 
 __global__ __launch_bounds__(256, 1) void attn_fwd_wide384_kernel(const AttnArgs a) {
   using C = WideCfg;
@@ -474,6 +411,25 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wide384_kernel(const AttnArgs
   bf16x8_t qf[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) qf[ks] = *(const bf16x8_t*)(qbase + (int64_t)qrow * a.ld_q + ks * 16 + h * 8);
+  if (a.q_cos) {   // wave-uniform: rotate the first q_rot_dim dims of this lane's query row (x_transformers partial rotary)
+    const int half = a.q_rot_dim >> 1;
+    const float* cr = a.q_cos + (int64_t)qrow * half;
+    const float* sr = a.q_sin + (int64_t)qrow * half;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int d0 = ks * 16 + h * 8;                 // this lane's 8 dims of k-step ks = pairs d0 / 2 .. d0 / 2 + 3
+      if (d0 < a.q_rot_dim) {
+        const float4 c4 = *(const float4*)(cr + (d0 >> 1)), s4 = *(const float4*)(sr + (d0 >> 1));
+        const float cs[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const float qa = bf16_to_f32((unsigned short)qf[ks][2 * pp]), qb = bf16_to_f32((unsigned short)qf[ks][2 * pp + 1]);
+          qf[ks][2 * pp] = (short)f32_to_bf16(qa * cs[pp] - qb * sn[pp]);
+          qf[ks][2 * pp + 1] = (short)f32_to_bf16(qb * cs[pp] + qa * sn[pp]);
+        }
+      }
+    }
+  }
 
   // ---- staging plan: piece i of this wave covers linear 16-byte chunks [(wave + 4 i) * 64, +64) of a tile ----
   int st_row[C::PPW], st_src[C::PPW], st_off[C::PPW];
@@ -994,6 +950,13 @@ int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
   return 0;
 }
 
+}  // namespace
+int tribe_internal_attn_d64_launch(const void* args, int64_t B, int relkey, hipStream_t s);   // attention_d64.hip
+namespace {
+
+thread_local const float* g_q_cos = nullptr;   // handed from tribe_internal_attention_fused_qrot to the launch below it (same thread)
+thread_local const float* g_q_sin = nullptr;
+thread_local int g_q_rot_dim = 0;
 int g_attn_wide384 = 1;   // DH = 384 variant: 1 = one wave per SIMD (32 rows x 384), 2 = key-split pairs, 0 = the 16-row kernel (tribe_attention_set_mode)
 
 template <int DH>
@@ -1030,6 +993,7 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
   a.qblocks = (int)((d->T + 127) / 128);
   a.n_bh = (int)(d->B * d->heads_q);
   a.qe = d->rel_qe; a.ld_qe = d->ld_rel_qe; a.qe_stride_h = d->rel_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
+  a.q_cos = g_q_cos; a.q_sin = g_q_sin; a.q_rot_dim = g_q_rot_dim;   // set only around tribe_internal_attention_fused_qrot
   hipStream_t s = (hipStream_t)stream;
 #ifdef TRIBE_ATTN_STAMPS
   if (d->rel_qe && d->dim_head == 384) return launch_attn_dh<384>(a, d->B, d->causal, s);   // rel_qe carries the stamp buffer
@@ -1039,14 +1003,31 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
     TRIBE_REQUIRE(d->rel_left >= 0 && d->rel_right >= 0 && d->rel_stride_h >= d->rel_left + d->rel_right + 1 &&
                       d->ld_rel_qe >= (int64_t)d->heads_q * d->rel_stride_h,
                   "tribe_attention_fwd_ex: bad relative_key table geometry");
-    return launch_attn<64, 0, 1>(a, d->B, s);
+    return g_attn_wide384 ? tribe_internal_attn_d64_launch(&a, d->B, 1, s) : launch_attn<64, 0, 1>(a, d->B, s);
   }
   switch (d->dim_head) {
-    case 64: return launch_attn_dh<64>(a, d->B, d->causal, s);
+    case 64: return (!d->causal && g_attn_wide384) ? tribe_internal_attn_d64_launch(&a, d->B, 0, s) : launch_attn_dh<64>(a, d->B, d->causal, s);
     case 128: return launch_attn_dh<128>(a, d->B, d->causal, s);
     case 192: return launch_attn_dh<192>(a, d->B, d->causal, s);
     default: return launch_attn_dh<384>(a, d->B, d->causal, s);
   }
+}
+
+// 1 when the next fused launch at this head size rotates Q itself if given the tables (the DH = 384 one-wave kernel)
+int tribe_internal_attention_rotates_q(int dim_head) { return dim_head == 384 && g_attn_wide384 == 1; }
+
+int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out, hipStream_t s);
+
+// as tribe_internal_attention_fused, with the partial rotary of Q (interleaved pairs) applied inside the kernel: q in `qkv` is NOT
+// rotated, k is.  Only valid while tribe_internal_attention_rotates_q(dim_head).
+int tribe_internal_attention_fused_qrot(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
+                                        const float* cos_tab, const float* sin_tab, int rot_dim, hipStream_t s) {
+  TRIBE_REQUIRE(tribe_internal_attention_rotates_q(dim_head) && cos_tab && sin_tab && rot_dim > 0 && rot_dim % 16 == 0 && rot_dim <= dim_head,
+                "tribe_internal_attention_fused_qrot: unsupported configuration");
+  g_q_cos = cos_tab; g_q_sin = sin_tab; g_q_rot_dim = rot_dim;
+  const int rc = tribe_internal_attention_fused(qkv, B, T, heads, dim_head, scale, out, s);
+  g_q_cos = g_q_sin = nullptr; g_q_rot_dim = 0;
+  return rc;
 }
 
 int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,

@@ -14,6 +14,9 @@ int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, in
                                    hipStream_t s);
 
 void tribe_internal_attention_set_wide384(int on);
+int tribe_internal_attention_rotates_q(int dim_head);
+int tribe_internal_attention_fused_qrot(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
+                                        const float* cos_tab, const float* sin_tab, int rot_dim, hipStream_t s);
 static int g_attn_mode = 0;  // 0 = fused kernel when the head size has one, 1 = always the 3-kernel (materialised) path
 extern "C" int tribe_attention_set_mode(int32_t mode) {
   TRIBE_REQUIRE(mode >= 0 && mode <= 3, "tribe_attention_set_mode: mode must be 0 (auto), 1 (materialised scores), 2 (fused, 16-row waves at every head size) or 3 (dim_head 384 on the key-split kernel)");
@@ -216,11 +219,20 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.role = TRIBE_ROLE_QKV;
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
-    // q heads and k heads are adjacent in the fused row: rotate the first 2*heads heads
-    rc = tribe_rotary_fwd(qkv, M, d->T, 3 * inner, 2 * d->heads, d->dim_head, d->rot_dim, d->cos_tab, d->sin_tab,
-                          d->rotary_interleaved, stream);
-    if (rc) return rc;
-    rc = tribe_attention_fwd(qkv, d->B, d->T, d->heads, d->dim_head, scale, ao, attn_ws, p.attn_bytes, stream);
+    // q heads and k heads are adjacent in the fused row.  The DH = 384 attention kernel rotates Q while it loads its Q fragments
+    // (interleaved pairs; bit-identical arithmetic), so only the k heads go through the stand-alone pass: half its 805 MB.
+    const bool q_in_attn = g_attn_mode == 0 && d->rot_dim > 0 && d->rotary_interleaved == 1 && d->rot_dim % 16 == 0 &&
+                           tribe_internal_attention_rotates_q(d->dim_head);
+    if (d->rot_dim > 0) {
+      rc = q_in_attn ? tribe_rotary_fwd(qkv + inner, M, d->T, 3 * inner, d->heads, d->dim_head, d->rot_dim, d->cos_tab, d->sin_tab,
+                                        d->rotary_interleaved, stream)
+                     : tribe_rotary_fwd(qkv, M, d->T, 3 * inner, 2 * d->heads, d->dim_head, d->rot_dim, d->cos_tab, d->sin_tab,
+                                        d->rotary_interleaved, stream);
+      if (rc) return rc;
+    }
+    rc = q_in_attn ? tribe_internal_attention_fused_qrot(qkv, d->B, d->T, d->heads, d->dim_head, scale, ao, d->cos_tab, d->sin_tab,
+                                                         d->rot_dim, (hipStream_t)stream)
+                   : tribe_attention_fwd(qkv, d->B, d->T, d->heads, d->dim_head, scale, ao, attn_ws, p.attn_bytes, stream);
     if (rc) return rc;
     g = gemm_zero();
     g.M = M; g.N = dim; g.K = inner;

@@ -221,6 +221,27 @@ def attention_gqa(qkv: torch.Tensor, B: int, T: int, heads_q: int, heads_kv: int
     return out
 
 
+def attention_relative_key(qkv: torch.Tensor, B: int, T: int, heads: int, dim_head: int, scale: float, qe: torch.Tensor,
+                           left: int, right: int) -> torch.Tensor:
+    """Bidirectional attention with the Wav2Vec-BERT relative_key bias (modeling_wav2vec2_bert.py:308-320):
+    score[i, j] = (q_i . k_j + qe[i, h, clamp(j - i, -left, right) + left]) * scale, on a fused [B*T, 3*heads*dim_head] buffer.
+    `qe` = q . E^T per query row and head, f32 [B*T, heads, stride >= left + right + 1]."""
+    _cuda(qkv, torch.bfloat16, "qkv")
+    _cuda(qe, torch.float32, "qe")
+    if qkv.numel() != B * T * 3 * heads * dim_head or qe.dim() != 3 or qe.shape[0] != B * T or qe.shape[1] != heads:
+        raise ValueError("attention_relative_key: qkv / qe have the wrong shape")
+    out = torch.empty(B * T, heads * dim_head, dtype=torch.bfloat16, device=qkv.device)
+    d = AttentionDesc()
+    base, width = qkv.data_ptr(), 3 * heads * dim_head
+    d.q, d.k, d.v = base, base + 2 * heads * dim_head, base + 4 * heads * dim_head
+    d.ld_q = d.ld_k = d.ld_v = width
+    d.out, d.ld_out = out.data_ptr(), heads * dim_head
+    d.B, d.T, d.heads_q, d.heads_kv, d.dim_head, d.causal, d.scale = B, T, heads, heads, dim_head, 0, scale
+    d.rel_qe, d.ld_rel_qe, d.rel_stride_h, d.rel_left, d.rel_right = qe.data_ptr(), heads * qe.shape[2], qe.shape[2], left, right
+    check(lib().tribe_attention_fwd_ex(C.byref(d), _stream()), "tribe_attention_fwd_ex")
+    return out
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
     _cuda(x, torch.float32, "x")
     _cuda(w, torch.float32, "w")

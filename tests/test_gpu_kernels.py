@@ -247,6 +247,56 @@ def test_attention(ops, B, T, h, d, mode):
     torch.testing.assert_close(out, want, rtol=2**-6, atol=3e-3)
 
 
+# dim_head 64 (the extractors) on the 64-row-per-wave kernel (mode 0) and on the 16-row kernel (mode 2): several 256-row query
+# blocks, ragged last key tile and last row tile, one sub-tile only (T = 20), a late deferred-max rescale.
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("B,T,h", [(1, 20, 2), (2, 257, 3), (1, 1000, 5), (1, 3000, 2), (3, 64, 1)])
+def test_attention_dim_head_64(ops, B, T, h, mode):
+    d = 64
+    g = torch.Generator().manual_seed(10)
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g))
+    if T >= 1000:
+        qkv.view(B, T, 3, h, d)[0, 37, 0, 0] *= 6.0
+        qkv.view(B, T, 3, h, d)[0, 900, 1, 0] = bf(qkv.view(B, T, 3, h, d)[0, 37, 0, 0] * 0.5)
+    ops.attention_set_mode(mode)
+    try:
+        out = ops.attention(_dev(qkv).bfloat16(), B, T, h, d, d**-0.5).float().cpu()
+    finally:
+        ops.attention_set_mode(0)
+    q, k, v = (t.transpose(1, 2) for t in qkv.view(B, T, 3, h, d).unbind(2))
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * d**-0.5
+    want = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).transpose(1, 2).reshape(B * T, h * d)
+    torch.testing.assert_close(out, want, rtol=2**-6, atol=3e-3)
+
+
+# relative_key bias of Wav2Vec-BERT (HF modeling_wav2vec2_bert.py:308-320: distance clamped to [-left, right], q . E[distance] added
+# before the scale).  The 64-row kernel adds the two out-of-band constants per row and gathers only inside the band; T = 3000 is the
+# extractor's 60 s chunk, (left, right) = (64, 8) its geometry, (5, 3) / (0, 0) / (100, 90) move the band edges across sub-tiles.
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("B,T,h,left,right", [(1, 3000, 2, 64, 8), (2, 300, 3, 64, 8), (1, 70, 2, 5, 3), (1, 500, 1, 0, 0), (1, 400, 2, 100, 90)])
+def test_attention_relative_key(ops, B, T, h, left, right, mode):
+    d = 64
+    g = torch.Generator().manual_seed(11)
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g))
+    npos = left + right + 1
+    stride = (npos + 7) // 8 * 8
+    emb = torch.randn(npos, d, generator=g) * 0.5
+    q, k, v = (t.transpose(1, 2) for t in qkv.view(B, T, 3, h, d).unbind(2))           # [B, h, T, d]
+    qe = torch.einsum("bhid,pd->bhip", q, emb)                                            # [B, h, T, npos]
+    qe_dev = torch.zeros(B * T, h, stride)
+    qe_dev[:, :, :npos] = qe.permute(0, 2, 1, 3).reshape(B * T, h, npos)
+    ops.attention_set_mode(mode)
+    try:
+        out = ops.attention_relative_key(_dev(qkv).bfloat16(), B, T, h, d, d**-0.5, _dev(qe_dev), left, right).float().cpu()
+    finally:
+        ops.attention_set_mode(0)
+    dist = (torch.arange(T)[None, :] - torch.arange(T)[:, None]).clamp(-left, right) + left     # [i, j]
+    bias = torch.gather(qe, 3, dist[None, None].expand(B, h, T, T))
+    sim = (torch.einsum("bhid,bhjd->bhij", q, k) + bias) * d**-0.5
+    want = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).transpose(1, 2).reshape(B * T, h * d)
+    torch.testing.assert_close(out, want, rtol=2**-6, atol=3e-3)
+
+
 @pytest.mark.parametrize("interleaved,legacy", [(True, False), (False, True)])
 def test_encoder_vs_oracle(ops, interleaved, legacy):
     """2-layer dim-768 encoder: HIP (bf16 operands, fp32 accumulate / residual) vs the fp32 oracle."""
