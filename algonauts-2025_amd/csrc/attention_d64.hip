@@ -142,6 +142,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs a) 
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
+  // The compiler waits for its own global loads at their first use -- inside the key loop, where its s_waitcnt vmcnt(0) would also
+  // drain the LDS-DMA loads of tile t + 2 it cannot see (issued a few instructions earlier): every tile then paid a full memory
+  // round trip.  Using the loaded values here pins those waits in front of the loop.
+#pragma unroll
+  for (int qt = 0; qt < C::QT; ++qt) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+    if (RELKEY) asm volatile("" : "+v"(c_left[qt]), "+v"(c_right[qt]));
+  }
+
   const int ntiles = (T + C::KV - 1) / C::KV;
   stage(0, 0);
   if (ntiles > 1) stage(1, C::KV);

@@ -199,7 +199,7 @@ def test_plugins_share_one_store_with_the_batch_loader(g11):
 
     snd = [Sound(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"a{e}.wav", timeline="t", extra={"subject": "sub-02"}) for e in range(2)]
     vid = [Video(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"v{e}.mkv", timeline="t", extra={"subject": "sub-02"}) for e in range(2)]
-    words = [Word(start=float(s), duration=float(d), text=f"w{i}", context=f"c{i}", timeline="t")
+    words = [Word(start=float(s), duration=float(d), text=f"w{i}", context=f"c{i}", timeline="t", extra={"subject": "sub-02"})
              for i, (s, d) in enumerate(zip(g11["word_start"], g11["word_dur"]))]
     text, audio, video = LLAMA3p2(device="cuda"), Wav2VecBert(device="cuda"), VJEPA2(device="cuda")
     for e in range(2):
@@ -240,7 +240,7 @@ def test_segment_dataset_with_all_five_features(g11):
 
     snd = [Sound(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"a{e}.wav", timeline="t", extra={"subject": "sub-02"}) for e in range(2)]
     vid = [Video(start=float(g11["dense_ev_start"][e]), duration=float(g11["dense_ev_dur"][e]), filepath=f"v{e}.mkv", timeline="t", extra={"subject": "sub-02"}) for e in range(2)]
-    words = [Word(start=float(s), duration=float(d), text=f"w{i}", context=f"c{i}", timeline="t")
+    words = [Word(start=float(s), duration=float(d), text=f"w{i}", context=f"c{i}", timeline="t", extra={"subject": "sub-02"})
              for i, (s, d) in enumerate(zip(g11["word_start"], g11["word_dur"]))]
     rec = FmriEvent(start=float(g11["fmri_start"]), duration=g11["fmri_data"].shape[1] * 1.49, filepath="sub-02.h5", frequency=1 / 1.49, subject="sub-02", timeline="t")
     other = FmriEvent(start=0.0, duration=10.0, filepath="sub-01.h5", frequency=1 / 1.49, subject="sub-01", timeline="u")
