@@ -229,8 +229,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sv[u][r] = s0[r]; sv[u][4 + r] = s1[r]; }
       }
+      // first read of this sub-tile's MFMA results by an instruction the compiler sees, so that it pads the MFMA-write -> VALU-read
+      // hazard; the inline-asm v_max3 links depend on it through pmax (see attention_d64.hip softmax_head)
+      pmax = fmaxf(pmax, fmaxf(sv[u][0], sv[u][4]));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pmax = max3f(pmax, sv[u][r], sv[u][4 + r]);
+      for (int r = 1; r < 4; ++r) pmax = max3f(pmax, sv[u][r], sv[u][4 + r]);
     }
     // the other three 16-lane groups hold the other keys of this query
     pmax = fmaxf(pmax, __shfl_xor(pmax, 16, 64));
@@ -345,18 +348,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 // fragments under the last S^T MFMAs, and the matrix pipe does not drain at the seams.
 // Diagnostic build only (-DTRIBE_ATTN_STAMPS, scripts/attn_stamps.py): s_memtime stamps at the phase boundaries of the key loop,
 // summed per wave into a side buffer whose pointer rides in desc.rel_qe.  Never quote the run time of that build; read the shares.
-#ifdef TRIBE_ATTN_STAMPS
-#define ATTN_STAMP(var)                                                                   \
-  do {                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-  } while (0)
-#define ATTN_STAMP_ADD(i, a, b) stamp_acc[i] += (b) - (a)
-#else
-#define ATTN_STAMP(var) do {} while (0)
-#define ATTN_STAMP_ADD(i, a, b) do {} while (0)
-#endif
 
 struct WideCfg {
   static constexpr int DH = 384, KS = 24, DT = 12, ROWB = 768, KV = 32, CHUNKS = 48;
@@ -951,12 +942,13 @@ int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
 }
 
 }  // namespace
-int tribe_internal_attn_d64_launch(const void* args, int64_t B, int relkey, hipStream_t s);   // attention_d64.hip
+int tribe_internal_attn_d64_launch(const void* args, int64_t B, int relkey, int variant, hipStream_t s);   // attention_d64.hip
 namespace {
 
 thread_local const float* g_q_cos = nullptr;   // handed from tribe_internal_attention_fused_qrot to the launch below it (same thread)
 thread_local const float* g_q_sin = nullptr;
 thread_local int g_q_rot_dim = 0;
+int g_attn_d64_variant = 0;   // DH = 64: 0 = by grid size, 1 = 4-wave kernel, 2 = anti-phase 8-wave kernel (attention_d64.hip)
 int g_attn_wide384 = 1;   // DH = 384 variant: 1 = one wave per SIMD (32 rows x 384), 2 = key-split pairs, 0 = the 16-row kernel (tribe_attention_set_mode)
 
 template <int DH>
@@ -969,6 +961,7 @@ int launch_attn_dh(const AttnArgs& a, int64_t B, int causal, hipStream_t s) {
 }  // namespace
 
 void tribe_internal_attention_set_wide384(int on) { g_attn_wide384 = on; }
+void tribe_internal_attention_set_d64_variant(int v) { g_attn_d64_variant = v; }
 
 // returns 1 if a fused kernel exists for this head size, else 0 (caller falls back to the 3-kernel path)
 int tribe_internal_attention_fused_supported(int dim_head) {
@@ -997,16 +990,17 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
   hipStream_t s = (hipStream_t)stream;
 #ifdef TRIBE_ATTN_STAMPS
   if (d->rel_qe && d->dim_head == 384) return launch_attn_dh<384>(a, d->B, d->causal, s);   // rel_qe carries the stamp buffer
+  if (d->rel_qe && d->dim_head == 64 && d->rel_left < 0) return tribe_internal_attn_d64_launch(&a, d->B, 0, g_attn_d64_variant, s);
 #endif
   if (d->rel_qe) {
     TRIBE_REQUIRE(d->dim_head == 64 && !d->causal, "tribe_attention_fwd_ex: the relative_key bias is built for dim_head 64, non-causal");
     TRIBE_REQUIRE(d->rel_left >= 0 && d->rel_right >= 0 && d->rel_stride_h >= d->rel_left + d->rel_right + 1 &&
                       d->ld_rel_qe >= (int64_t)d->heads_q * d->rel_stride_h,
                   "tribe_attention_fwd_ex: bad relative_key table geometry");
-    return g_attn_wide384 ? tribe_internal_attn_d64_launch(&a, d->B, 1, s) : launch_attn<64, 0, 1>(a, d->B, s);
+    return g_attn_wide384 ? tribe_internal_attn_d64_launch(&a, d->B, 1, g_attn_d64_variant, s) : launch_attn<64, 0, 1>(a, d->B, s);
   }
   switch (d->dim_head) {
-    case 64: return (!d->causal && g_attn_wide384) ? tribe_internal_attn_d64_launch(&a, d->B, 0, s) : launch_attn_dh<64>(a, d->B, d->causal, s);
+    case 64: return (!d->causal && g_attn_wide384) ? tribe_internal_attn_d64_launch(&a, d->B, 0, g_attn_d64_variant, s) : launch_attn_dh<64>(a, d->B, d->causal, s);
     case 128: return launch_attn_dh<128>(a, d->B, d->causal, s);
     case 192: return launch_attn_dh<192>(a, d->B, d->causal, s);
     default: return launch_attn_dh<384>(a, d->B, d->causal, s);

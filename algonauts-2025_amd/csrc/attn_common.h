@@ -76,3 +76,18 @@ __device__ __forceinline__ float pair_sum(float x) {
 }
 
 }  // namespace
+
+// Diagnostic build only (-DTRIBE_ATTN_STAMPS, scripts/attn_stamps.py): s_memtime stamps at the phase boundaries of a key loop, summed per
+// wave into a side buffer whose pointer rides in desc.rel_qe.  Never quote the run time of that build; read the shares.
+#ifdef TRIBE_ATTN_STAMPS
+#define ATTN_STAMP(var)                                                                   \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#define ATTN_STAMP_ADD(i, a, b) stamp_acc[i] += (b) - (a)
+#else
+#define ATTN_STAMP(var) do {} while (0)
+#define ATTN_STAMP_ADD(i, a, b) do {} while (0)
+#endif

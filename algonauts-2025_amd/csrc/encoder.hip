@@ -14,13 +14,15 @@ int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, in
                                    hipStream_t s);
 
 void tribe_internal_attention_set_wide384(int on);
+void tribe_internal_attention_set_d64_variant(int v);
 int tribe_internal_attention_rotates_q(int dim_head);
 int tribe_internal_attention_fused_qrot(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
                                         const float* cos_tab, const float* sin_tab, int rot_dim, hipStream_t s);
 static int g_attn_mode = 0;  // 0 = fused kernel when the head size has one, 1 = always the 3-kernel (materialised) path
 extern "C" int tribe_attention_set_mode(int32_t mode) {
-  TRIBE_REQUIRE(mode >= 0 && mode <= 3, "tribe_attention_set_mode: mode must be 0 (auto), 1 (materialised scores), 2 (fused, 16-row waves at every head size) or 3 (dim_head 384 on the key-split kernel)");
+  TRIBE_REQUIRE(mode >= 0 && mode <= 5, "tribe_attention_set_mode: mode must be 0 (auto), 1 (materialised scores), 2 (fused, 16-row waves at every head size), 3 (dim_head 384 on the key-split kernel), 4 / 5 (dim_head 64 on the 4-wave / the anti-phase 8-wave kernel)");
   tribe_internal_attention_set_wide384(mode == 2 ? 0 : (mode == 3 ? 2 : 1));
+  tribe_internal_attention_set_d64_variant(mode == 4 ? 1 : (mode == 5 ? 2 : 0));
   g_attn_mode = mode == 1 ? 1 : 0;
   return 0;
 }

@@ -282,7 +282,8 @@ def segment_mean(x: torch.Tensor, B: int, T: int, start: torch.Tensor | None, le
 
 
 def attention_set_mode(mode: int) -> None:
-    """0 = fused kernel (default), 1 = materialised-scores path (cross-check)."""
+    """0 = fused kernels, picked per head size and grid (default); 1 = materialised-scores path (cross-check); 2 = the 16-row-per-wave
+    kernel at every head size; 3 = dim_head 384 on the key-split kernel; 4 / 5 = dim_head 64 on the 4-wave / the anti-phase 8-wave kernel."""
     check(lib().tribe_attention_set_mode(mode), "tribe_attention_set_mode")
 
 

@@ -21,7 +21,7 @@ for name, B, T, H, rel in (("vjepa2 clips=1", 1, 8192, 22, False), ("vjepa2 clip
     qe = torch.randn(B * T, H, 80, generator=g, device="cuda") if rel else None
     flop = 4.0 * T * H * D * B * T
     ref = None
-    for mode, label in ((2, "16-row waves"), (0, "64-row waves")):
+    for mode, label in ((2, "16-row waves"), (4, "64-row waves x 4"), (5, "64-row wave pairs"), (0, "auto")):
         ops.attention_set_mode(mode)
         run = (lambda: ops.attention_relative_key(qkv, B, T, H, D, D**-0.5, qe, 64, 8)) if rel else (lambda: ops.attention(qkv, B, T, H, D, D**-0.5))
         for _ in range(3):
@@ -39,7 +39,7 @@ for name, B, T, H, rel in (("vjepa2 clips=1", 1, 8192, 22, False), ("vjepa2 clip
         err = float((y.float() - ref).abs().max())
         out.setdefault(name, {"B": B, "T": T, "heads": H, "gflop": flop / 1e9})[label] = {
             "ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1), "frac_of_2500": round(flop / ms / 1e9 / 2500, 4), "max_abs_diff_vs_16row": err}
-        print(f"{name:18s} {label:14s} {ms:8.4f} ms  {flop / ms / 1e9:7.1f} TFLOP/s  {flop / ms / 1e9 / 2500:6.1%} of peak   max|diff| {err:.2e}", flush=True)
+        print(f"{name:18s} {label:18s} {ms:8.4f} ms  {flop / ms / 1e9:7.1f} TFLOP/s  {flop / ms / 1e9 / 2500:6.1%} of peak   max|diff| {err:.2e}", flush=True)
 ops.attention_set_mode(0)
 if len(sys.argv) > 1:
     Path(sys.argv[1]).write_text(json.dumps(out, indent=1))
