@@ -478,7 +478,12 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
     TRIBE_REQUIRE(!d->row_sumsq || d->ld_row_sumsq >= d->N / 64, "tribe_gemm_bf16: ld_row_sumsq must cover N / 64 slots");
   }
   // tile selection: 256^2 tiles when both extents fill them and the grid still covers the chip, else 128^2
-  int use_big = (d->M >= 256 && d->N >= 256 && ((d->M + 255) / 256) * ((d->N + 255) / 256) * nz >= 96);
+  const int64_t t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256) * nz, t128 = ((d->M + 127) / 128) * ((d->N + 127) / 128) * nz;
+  int use_big = (d->M >= 256 && d->N >= 256 && t256 >= 96);
+  // Narrow, short-K products whose 256^2 grid is under two rounds of the 256 CUs (ViT-g attention projection: 8192 x 1408 x 1408 =
+  // 192 tiles) run faster on 128^2 tiles (60 -> 47 us; profiles/r02_o_gemm_shapes.txt); with K > 2048 or N > 2048 the 256^2 tiles'
+  // higher operand reuse wins back more than the idle CUs cost.
+  if (use_big && t256 < 512 && t128 >= 512 && d->K <= 2048 && d->N <= 2048) use_big = 0;
   if (d->tile_hint == 1) use_big = 0;
   if (d->tile_hint == 2) use_big = 1;
   const int64_t bm = use_big ? big::BM : small::BM, bn = use_big ? big::BN : small::BN;

@@ -181,7 +181,7 @@ class VJEPA2(HbmFeaturePlugin):
 
     name: tp.Literal["VJEPA2"] = "VJEPA2"
     pretrained: str = "facebook/vjepa2-vitg-fpc64-256"    # video.py:247-254; resolved from the local HF cache only
-    clips_per_launch: int = 2
+    clips_per_launch: int = 4   # 37.6 ms per clip at 4, 41.3 at 2, 44.9 at 1 (profiles/r02_p_config3_e2e.txt, r02_m_extractor_bench.txt)
     _EVENT_TYPE: tp.ClassVar[str] = "Video"
     _KIND: tp.ClassVar[str] = "sampled"
     _PASS_EVENT_DURATION: tp.ClassVar[bool] = True

@@ -4,7 +4,7 @@ steps at 2 Hz) of one subject, full-size architectures with random weights (chec
   audio  3 chunks of <= 60 s (3000 + 3000 + 1450 fbank frames) -> Wav2Vec-BERT 2.0 (audio.py:253-263)
   text   ~370 words, each with a 1024-token context -> Llama-3.2-3B (text.py:204-256, batches of 8)
   -> HBM feature store -> segment loader -> FmriEncoder (3072 x 8 layers) -> [1, 1000, 100].
-GPU box:  python scripts/e2e_bench.py [fp8]      ("fp8": e4m3 Linear GEMMs in Llama and V-JEPA2)"""
+GPU box:  python scripts/e2e_bench.py [fp8] [clips=N]      ("fp8": e4m3 Linear GEMMs in Llama and V-JEPA2; N clips per V-JEPA2 launch, default 4)"""
 import sys
 import time
 from pathlib import Path
@@ -19,7 +19,8 @@ from data_utils.events import Fmri, Sound, Video, Word  # noqa: E402
 from data_utils.gpu_loader import FeatureSpec, GpuSegmentLoader, HbmFeatureStore  # noqa: E402
 from data_utils.segments import Segment  # noqa: E402
 
-fp8 = len(sys.argv) > 1 and sys.argv[1] == "fp8"
+fp8 = "fp8" in sys.argv[1:]
+CLIPS = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("clips=")), 4)   # V-JEPA2 clips per launch
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
 
@@ -43,8 +44,8 @@ T_steps, n_words, ctx = 298, 368, 1024
 
 def run_video():
     out = []
-    for i in range(0, T_steps, 2):
-        clips = torch.randn(min(2, T_steps - i), 64, 3, 256, 256, device=dev)
+    for i in range(0, T_steps, CLIPS):
+        clips = torch.randn(min(CLIPS, T_steps - i), 64, 3, 256, 256, device=dev)
         out.append(vj.hidden_state_means(clips))                    # [b, 41, 1408]
     return torch.cat(out).permute(1, 2, 0).contiguous()             # [41, 1408, 298]
 
