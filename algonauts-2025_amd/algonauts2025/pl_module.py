@@ -79,19 +79,23 @@ class BrainModule(nn.Module):
                 metric.update(pred, target)
             self.log(key, metric)
 
-    def _run_step(self, batch: SegmentData, batch_idx: int, step_name: str):
+    def _run_step(self, batch: SegmentData, batch_idx: int, step_name: str, outputs: bool = True):
+        """pl_module.py:107-124.  `outputs=False` (training_step, which only returns the loss) skips the host copies of the prediction and
+        the target: 130 MB over PCIe and a device synchronisation per step at B = 16 that nothing reads."""
         target = batch.data["fmri"]                 # [B, V, T']
         pred = self.forward(batch)                  # [B, V, T']
         n = pred.shape[0]
         loss = self._primary_loss(pred, target.to(pred.dtype)) + self._alignment_term(batch, step_name, n)
         self.log(f"{step_name}/loss", loss, batch_size=n)
         self._feed_metrics(step_name, pred, target, batch.data["subject_id"])
+        if not outputs:
+            return loss, None, None
         return loss, pred.detach().cpu(), target.detach().cpu()
 
     def training_step(self, batch: SegmentData, batch_idx: int):
         """pl_module.py:126-128: returns the loss tensor; `loss.backward()` then runs the HIP backward kernels through
         the autograd functions of modeling_utils/autograd.py (MSE / Pearson loss + optional InfoNCE alignment)."""
-        return self._run_step(batch, batch_idx, step_name="train")[0]
+        return self._run_step(batch, batch_idx, step_name="train", outputs=False)[0]
 
     def validation_step(self, batch: SegmentData, batch_idx: int):
         return self._run_step(batch, batch_idx, step_name="val")[1:]

@@ -261,6 +261,21 @@ __global__ __launch_bounds__(256) void rowsum_scatter_kernel(const float* __rest
   if (lane == 0) atomicAdd(out + idx[b] * V + v, acc);
 }
 
+// dst[idx[b]][e] += src[b][e] for b = 0 .. B - 1 IN ORDER: one thread owns element e (4 floats) of every destination slab, so the sum
+// of the samples of one subject has a fixed order (atomics would not) and nothing races
+__global__ __launch_bounds__(256) void slab_scatter_sum_kernel(const float* __restrict__ src, int64_t B, int64_t n4, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n4) return;
+  for (int64_t b = 0; b < B; ++b) {
+    const float4 v = load_nt_f4(src + (b * n4 + e) * 4);
+    float4* d = (float4*)dst + idx[b] * n4 + e;
+    float4 acc = *d;
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    *d = acc;
+  }
+}
+
 __global__ void scale_cols_kernel(const float* __restrict__ x, const float* __restrict__ rs, int64_t M, int64_t N, float* __restrict__ y) {
   const int64_t total = M * N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
@@ -521,6 +536,15 @@ extern "C" int tribe_adaptive_avg_pool_bwd(const float* dy, int64_t rows, int64_
 extern "C" int tribe_rowsum_scatter(const float* x, int64_t B, int64_t V, int64_t T, const int64_t* idx, float* out, void* stream) {
   TRIBE_REQUIRE(x && idx && out && B > 0 && V > 0 && T > 0 && B < 65536, "tribe_rowsum_scatter: bad argument");
   hipLaunchKernelGGL(rowsum_scatter_kernel, dim3((unsigned)((B * V + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, B, V, T, idx, out);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_slab_scatter_sum(const float* src, int64_t B, int64_t n, const int64_t* idx, float* dst, void* stream) {
+  TRIBE_REQUIRE(src && idx && dst && B > 0 && n > 0 && n % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                "tribe_slab_scatter_sum: needs n %% 4 == 0 and 16-byte aligned slabs");
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(slab_scatter_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, B, n4, idx, dst);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

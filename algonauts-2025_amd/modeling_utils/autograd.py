@@ -405,10 +405,18 @@ class VoxelHead(torch.autograd.Function):
         # dW[s, c, v] += sum_t x[b, t, c] dy[b, v, t]  for every sample b of subject s:  A = x_b^T [C, Tp], B = dy_b [V, Tp]
         xT = transpose_bf16(x, B, T, Cc, T * Cp, Cp)                                        # [B, C, Tp]
         dyb = ops.pack_weight(dy.reshape(B * V, T), cols_pad=Tp)                            # [B*V, Tp] bf16
+        # one batched launch for the B per-sample products, then the samples of a subject summed in sample order on the device: no
+        # device -> host read of `subjects` (it stalled the launch queue once per step) and B / 256-CU-filling tiles instead of B serial
+        # 32-tile GEMMs chained through dW
         dw = torch.zeros(S, Cc, V, dtype=torch.float32, device=dev)
-        for b, s in enumerate(subjects.tolist()):
-            _gemm(xT, dyb, dw, lda=Tp, ldb=Tp, ldc=V, M=Cc, N=V, K=Tp, a_off=b * Cc * Tp, b_off=b * V * Tp, c_off=s * Cc * V, res=dw,
-                  ldres=V)
+        if (Cc * V) % 4 == 0:
+            dwb = torch.empty(B, Cc, V, dtype=torch.float32, device=dev)
+            _gemm(xT, dyb, dwb, lda=Tp, ldb=Tp, ldc=V, M=Cc, N=V, K=Tp, batch1=B, sA=(Cc * Tp, 0), sB=(V * Tp, 0), sC=(Cc * V, 0))
+            check(lib().tribe_slab_scatter_sum(dwb.data_ptr(), B, Cc * V, subjects.data_ptr(), dw.data_ptr(), _s()), "tribe_slab_scatter_sum")
+        else:
+            for b, s in enumerate(subjects.tolist()):
+                _gemm(xT, dyb, dw, lda=Tp, ldb=Tp, ldc=V, M=Cc, N=V, K=Tp, a_off=b * Cc * Tp, b_off=b * V * Tp, c_off=s * Cc * V, res=dw,
+                      ldres=V)
         db = None
         if ctx.has_bias:
             db = torch.zeros(S, V, dtype=torch.float32, device=dev)

@@ -422,6 +422,10 @@ int tribe_mse_bwd(const float* pred, const float* truth, int64_t n, const float*
 int tribe_adaptive_avg_pool_bwd(const float* dy, int64_t rows, int64_t T_in, int64_t T_out, float* dx, void* stream);
 /* out[idx[b], v] += sum_t x[b, v, t]   (SubjectLayers bias gradient) */
 int tribe_rowsum_scatter(const float* x, int64_t B, int64_t V, int64_t T, const int64_t* idx, float* out, void* stream);
+/* dst[idx[b], :] += src[b, :] for b = 0 .. B-1 in that order (deterministic; no atomics): src f32 [B, n], dst f32 [S, n], n % 4 == 0.
+ * SubjectLayers weight gradient: the per-sample products x_b^T dy_b of one batched GEMM summed into their subject's slab
+ * (modeling_utils/models/common.py:60-76 is the forward it differentiates). */
+int tribe_slab_scatter_sum(const float* src, int64_t B, int64_t n, const int64_t* idx, float* dst, void* stream);
 /* y = x * rs (columns), f32 [M, N]; rs NULL = copy */
 int tribe_scale_cols_fwd(const float* x, const float* rs, int64_t M, int64_t N, float* y, void* stream);
 /* PearsonLoss backward (losses.py:17-42) on [B, V, T] views (element strides sb, sv, st shared by pred / true / dpred
