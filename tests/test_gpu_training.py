@@ -79,6 +79,49 @@ def test_autograd_blocks_vs_torch():
     torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("V", [20, 23])   # C * V % 4 == 0: one batched GEMM + ordered device scatter sum; otherwise the per-sample chain
+def test_subject_head_gradients_with_repeated_subjects(V):
+    """SubjectLayers (modeling_utils/models/common.py:60-76 in the reference) backward when several samples share a subject: dW[s] is
+    the sum over those samples, bias likewise; launch to launch the result is bit-identical (fixed summation order, no atomics)."""
+    from modeling_utils import autograd as ag
+
+    g = torch.Generator().manual_seed(5)
+    B, T, C, S = 7, 40, 64, 3
+    subjects = torch.tensor([2, 0, 2, 1, 2, 0, 2])
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = bf(torch.randn(B, T, C, generator=g)); w = bf(torch.randn(S, C, V, generator=g) / C**0.5); bias = torch.randn(S, V, generator=g)
+    dy = bf(torch.randn(B, V, T, generator=g))
+    xt, wt, bt = (t.clone().requires_grad_() for t in (x, w, bias))
+    (torch.einsum("btc,bcv->bvt", xt, wt[subjects]) + bt[subjects][:, :, None]).backward(dy)
+    grads = []
+    for _ in range(2):
+        xg = x.cuda().bfloat16().requires_grad_(); wg, bg = (t.cuda().requires_grad_() for t in (w, bias))
+        y = ag.VoxelHead.apply(xg, wg, bg, subjects.cuda())
+        y.backward(dy.cuda())
+        grads.append((xg.grad.float().cpu(), wg.grad.cpu(), bg.grad.cpu()))
+    for name, got, want in zip(("dx", "dw", "db"), grads[0], (xt.grad, wt.grad, bt.grad)):
+        assert _rel(got, want) < 2e-2, name
+    assert torch.equal(grads[0][1], grads[1][1])
+
+
+def test_slab_scatter_sum_is_the_ordered_sum():
+    """tribe_slab_scatter_sum: dst[idx[b]] += src[b] for b in order == the same loop on the host, bit for bit."""
+    from tribe_hip._lib import check, lib
+
+    g = torch.Generator().manual_seed(6)
+    B, n, S = 9, 4 * 331, 4
+    src = torch.randn(B, n, generator=g) * torch.logspace(-3, 3, B)[:, None]      # magnitudes that make the order matter
+    idx = torch.tensor([1, 3, 1, 1, 0, 3, 1, 0, 1])
+    want = torch.zeros(S, n)
+    for b in range(B):
+        want[idx[b]] += src[b]
+    dst, src_d, idx_d = torch.zeros(S, n, device="cuda"), src.cuda(), idx.cuda()
+    check(lib().tribe_slab_scatter_sum(src_d.data_ptr(), B, n, idx_d.data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream),
+          "tribe_slab_scatter_sum")
+    assert torch.equal(dst.cpu(), want)
+    assert lib().tribe_slab_scatter_sum(src_d.data_ptr(), B, 6, idx_d.data_ptr(), dst.data_ptr(), 0) != 0   # n % 4 != 0 is refused
+
+
 @pytest.mark.parametrize("cfg_kw", [{}, {"layer_aggregation": "mean", "subject_embedding": True}, {"feature_aggregation": "sum"}])
 def test_training_step_gradients_vs_oracle(cfg_kw):
     """BrainModule.training_step + loss.backward(): loss and every parameter gradient vs the fp32 CPU oracle graph."""
