@@ -23,6 +23,7 @@
 namespace {
 
 constexpr int BK = 64;
+typedef __attribute__((ext_vector_type(4))) short s16x4_tn;   // operand of ds_read_b64_tr_b16
 constexpr int TRIBE_ROLE_EXT = 100;  // kernel instantiation carrying the extended epilogue (see gemm_common.h)
 
 // =============================================================================================
@@ -60,7 +61,12 @@ constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // 128 KiB
 #define TRIBE_STAMP_ACC(slot, t_from, t_to) do { } while (0)
 #endif
 
-template <int OUT_BF16, int ROLE>
+// TN = 1 (desc.trans_ab): the operands arrive TRANSPOSED -- At [K, M] and Bt [K, N] row-major, the layout of the two factors of a
+// weight gradient dW = dY^T X as the forward left them -- and C[m][n] = sum_k At[k][m] Bt[k][n].  Same schedule, same LDS bytes; what
+// changes is the LDS image (per half-tile [64 k][128 out] rows of 256 bytes, 16-byte chunks XOR-swizzled by (k & 7) << 1 on the source
+// side) and the fragment reads (two ds_read_b64_tr_b16 per fragment instead of one ds_read_b128: the hardware transposes; A and B use
+// the same k order inside an MFMA, so the sum is unchanged).  Replaces the explicit bf16 transposes of the wgrad operands.
+template <int OUT_BF16, int ROLE, int TN = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
   using namespace big;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,28 +97,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int ra = j * 128 + h * 64 + wave * 8;
-      const int rb = (2 * j + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8;
-      int64_t gr = m0 + ra + srow; gr = gr < g.M ? gr : g.M - 1;  // clamp: edge rows re-read a valid row, stores are masked
-      int64_t gc = n0 + rb + srow; gc = gc < g.N ? gc : g.N - 1;
-      a_src[h][j] = A + gr * g.lda + schunk * 8;
-      b_src[h][j] = B + gc * g.ldb + schunk * 8;
-      a_lds[h][j] = ra * 128;
-      b_lds[h][j] = A_BYTES + rb * 128;
+      if (TN) {
+        // half-image h of an operand: [64 k][128 out] = 16 pieces of 4 k-rows; piece p = 8 j + wave; lane l fills physical chunk l & 15
+        // of k-row 4 p + (l >> 4) from the logical chunk the swizzle maps there.  Logical chunk c of A's half h holds tile rows
+        // (c >> 3) * 128 + h * 64 + (c & 7) * 8 .. + 7 (the two wave groups wr), of B's half h tile columns (c >> 2) * 64 + h * 32 +
+        // (c & 3) * 8 .. + 7 (the four wc): exactly the rows / columns phase h reads.
+        const int piece = 8 * j + wave, krow = 4 * piece + (lane >> 4);
+        const int lc = (lane & 15) ^ ((krow & 7) << 1);
+        int64_t gm = m0 + (lc >> 3) * 128 + h * 64 + (lc & 7) * 8; gm = gm + 8 <= g.M ? gm : g.M - 8;   // clamp to the last whole chunk
+        int64_t gn = n0 + (lc >> 2) * 64 + h * 32 + (lc & 3) * 8; gn = gn + 8 <= g.N ? gn : g.N - 8;
+        a_src[h][j] = A + (int64_t)krow * g.lda + gm;
+        b_src[h][j] = B + (int64_t)krow * g.ldb + gn;
+        a_lds[h][j] = h * 16384 + piece * 1024;
+        b_lds[h][j] = A_BYTES + h * 16384 + piece * 1024;
+      } else {
+        const int ra = j * 128 + h * 64 + wave * 8;
+        const int rb = (2 * j + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8;
+        int64_t gr = m0 + ra + srow; gr = gr < g.M ? gr : g.M - 1;  // clamp: edge rows re-read a valid row, stores are masked
+        int64_t gc = n0 + rb + srow; gc = gc < g.N ? gc : g.N - 1;
+        a_src[h][j] = A + gr * g.lda + schunk * 8;
+        b_src[h][j] = B + gc * g.ldb + schunk * 8;
+        a_lds[h][j] = ra * 128;
+        b_lds[h][j] = A_BYTES + rb * 128;
+      }
     }
 
   // which: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1
   auto stage = [&](int which, int buf, int kt) {
     char* base = smem + buf * BUF_BYTES;
-    const int koff = kt * BK;
+    const int64_t koff_a = TN ? (int64_t)kt * BK * g.lda : (int64_t)kt * BK;   // K runs along the rows of a transposed operand
+    const int64_t koff_b = TN ? (int64_t)kt * BK * g.ldb : (int64_t)kt * BK;
     if (which == 0 || which == 3) {
       const int h = which == 3;
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][0] + koff), (lptr_t)(base + a_lds[h][0]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][1] + koff), (lptr_t)(base + a_lds[h][1]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][0] + koff_a), (lptr_t)(base + a_lds[h][0]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][1] + koff_a), (lptr_t)(base + a_lds[h][1]), 16, 0, 0);
     } else {
       const int h = which == 2;
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][0] + koff), (lptr_t)(base + b_lds[h][0]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][1] + koff), (lptr_t)(base + b_lds[h][1]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][0] + koff_b), (lptr_t)(base + b_lds[h][0]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][1] + koff_b), (lptr_t)(base + b_lds[h][1]), 16, 0, 0);
     }
   };
 
@@ -129,15 +151,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
 
   bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
 
+  // TN fragment reads: lane i of a 16-lane group supplies k-row 4 fq + (i >> 2) (and + 16) of the k-step and 4 of the fragment's 16
+  // tile rows; after the hardware transpose lane (frow, fq) holds k = {4 fq .. + 3, 16 + 4 fq .. + 3} of tile row frow, for A and B alike.
+  // Fragment i of A's half image sits at logical chunks wr * 8 + 2 i (+ 1), fragment j of B's at wc * 4 + 2 j (+ 1).
+  const int tq = frow >> 2, tp = frow & 3;
+  const int t_row = 4 * fq + tq, t_sw = (t_row & 7) << 1;
+  int ta_off[4], tb_off[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ta_off[i] = t_row * 256 + (((wr * 8 + 2 * i + (tp >> 1)) ^ t_sw) << 4) + (tp & 1) * 8;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) tb_off[j] = A_BYTES + t_row * 256 + (((wc * 4 + 2 * j + (tp >> 1)) ^ t_sw) << 4) + (tp & 1) * 8;
+  auto tr_frag = [&](const char* p) -> bf16x8_t {   // k-rows r and r + 16 of one k-step
+    const s16x4_tn lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_tn*)(p));
+    const s16x4_tn hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_tn*)(p + 16 * 256));
+    bf16x8_t f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+    return f;
+  };
+
 #define TRIBE_LDS_A(base, MH)                                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
-    fa[i][0] = *(const bf16x8_t*)((base) + a_rd + (MH) * 8192 + i * 2048 + coff0);             \
-    fa[i][1] = *(const bf16x8_t*)((base) + a_rd + (MH) * 8192 + i * 2048 + coff1);             \
+    if (TN) {                                                                                  \
+      fa[i][0] = tr_frag((base) + (MH) * 16384 + ta_off[i]);                                   \
+      fa[i][1] = tr_frag((base) + (MH) * 16384 + ta_off[i] + 32 * 256);                        \
+    } else {                                                                                   \
+      fa[i][0] = *(const bf16x8_t*)((base) + a_rd + (MH) * 8192 + i * 2048 + coff0);           \
+      fa[i][1] = *(const bf16x8_t*)((base) + a_rd + (MH) * 8192 + i * 2048 + coff1);           \
+    }                                                                                          \
   }
 #define TRIBE_LDS_B(base, NH, FB)                                                              \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-    FB[j][0] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff0);             \
-    FB[j][1] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff1);             \
+    if (TN) {                                                                                  \
+      FB[j][0] = tr_frag((base) + (NH) * 16384 + tb_off[j]);                                   \
+      FB[j][1] = tr_frag((base) + (NH) * 16384 + tb_off[j] + 32 * 256);                        \
+    } else {                                                                                   \
+      FB[j][0] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff0);           \
+      FB[j][1] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff1);           \
+    }                                                                                          \
   }
 #define TRIBE_MMA(MH, NH, FB)                                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
@@ -454,7 +505,7 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
                     d->sB0 % 8 == 0,
                 "tribe_gemm_bf16: lda/ldb/batch strides must be multiples of 8 elements (16-byte rows)");
   TRIBE_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0, "tribe_gemm_bf16: A/B must be 16-byte aligned");
-  TRIBE_REQUIRE(d->lda >= d->K && d->ldb >= d->K && d->ldc >= ((d->act == TRIBE_ACT_SWIGLU || d->act == TRIBE_ACT_GLU) ? d->N / 2 : d->N),
+  TRIBE_REQUIRE((d->trans_ab || (d->lda >= d->K && d->ldb >= d->K)) && d->ldc >= ((d->act == TRIBE_ACT_SWIGLU || d->act == TRIBE_ACT_GLU) ? d->N / 2 : d->N),
                 "tribe_gemm_bf16: leading dimension too small");
   TRIBE_REQUIRE((d->act != TRIBE_ACT_SWIGLU && d->act != TRIBE_ACT_GLU) || (d->N % 2 == 0 && !d->res && !d->rowadd && !d->gadd && d->bias_mode != TRIBE_BIAS_ROW),
                 "tribe_gemm_bf16: SWIGLU needs an even N and no residual / row adds");
@@ -486,6 +537,14 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   if (use_big && t256 < 512 && t128 >= 512 && d->K <= 2048 && d->N <= 2048) use_big = 0;
   if (d->tile_hint == 1) use_big = 0;
   if (d->tile_hint == 2) use_big = 1;
+  if (d->trans_ab) {
+    TRIBE_REQUIRE(d->M >= 8 && d->N >= 8 && d->M % 8 == 0 && d->N % 8 == 0 && d->lda >= d->M && d->ldb >= d->N,
+                  "tribe_gemm_bf16: trans_ab takes At [K, M] and Bt [K, N] with M and N multiples of 8 and lda >= M, ldb >= N");
+    TRIBE_REQUIRE(!d->aux && d->act != TRIBE_ACT_SWIGLU && d->act != TRIBE_ACT_GLU && d->act != TRIBE_ACT_SILU && d->act != TRIBE_ACT_GELU_BWD &&
+                      !d->gather_a && !d->gather_b,
+                  "tribe_gemm_bf16: trans_ab supports the plain epilogue operators and no operand gather");
+    use_big = 1;
+  }
   const int64_t bm = use_big ? big::BM : small::BM, bn = use_big ? big::BN : small::BN;
   const int64_t tiles_m = (d->M + bm - 1) / bm, tiles_n = (d->N + bn - 1) / bn;
   TRIBE_REQUIRE(tiles_m * tiles_n < (1ll << 31) && nz < 65536, "tribe_gemm_bf16: grid too large");
@@ -509,6 +568,21 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
     if (use_big) TRIBE_GEMM_LAUNCH_K(gemm_nt_256x256x64, 512, big::SMEM_BYTES, BF, ROLE);                    \
     else TRIBE_GEMM_LAUNCH_K(gemm_nt_128x128x64, 256, small::SMEM_BYTES, BF, ROLE);                          \
   } while (0)
+  if (d->trans_ab) {   // transposed operands: the 256^2 kernel only, plain epilogue operators
+    static bool tn_attr_done = false;
+    if (!tn_attr_done) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256x256x64<0, TRIBE_ROLE_GENERIC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256x256x64<1, TRIBE_ROLE_GENERIC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM_BYTES);
+      tn_attr_done = true;
+    }
+    if (d->c_dtype == TRIBE_BF16)
+      hipLaunchKernelGGL((gemm_nt_256x256x64<1, TRIBE_ROLE_GENERIC, 1>), grid, dim3(512, 1, 1), big::SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
+    else
+      hipLaunchKernelGGL((gemm_nt_256x256x64<0, TRIBE_ROLE_GENERIC, 1>), grid, dim3(512, 1, 1), big::SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
+    prof_after(slot, s);
+    TRIBE_LAUNCH_CHECK();
+    return 0;
+  }
   const bool bf = d->c_dtype == TRIBE_BF16;
   const bool ext = d->aux != nullptr || d->act == TRIBE_ACT_SWIGLU || d->act == TRIBE_ACT_GLU || d->act == TRIBE_ACT_SILU ||
                    d->act == TRIBE_ACT_GELU_BWD;

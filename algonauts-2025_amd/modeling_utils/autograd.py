@@ -4,7 +4,8 @@ dense gradients, streaming kernels for the rest); torch.autograd only orders the
 Conventions: activations that feed a GEMM are bf16 `[M, K]`; the residual stream and all parameter gradients are f32.
 For Y = X W^T (X [M, K], W [N, K]):
     dX = dY W          -> NT GEMM with A = dY [M, N],   B = W^T [K, N]   (W^T packed once per weight version)
-    dW = dY^T X        -> NT GEMM with A = dY^T [N, M], B = X^T [K, M]   (transposes by tribe_transpose_bf16)
+    dW = dY^T X        -> the same kernel with transposed operands (desc.trans_ab: dY and X read as they lie; `wgrad` below), or, for
+                          shapes outside it, NT GEMM with A = dY^T [N, M], B = X^T [K, M] after tribe_transpose_bf16
     db = column sums of dY.
 Reference semantics followed: pl_module.py:126-128 (training_step = _run_step loss -> Lightning backward),
 model.py:113-174 (forward graph), x_transformers encoder (oracle/xt_encoder.py).
@@ -29,9 +30,10 @@ def _s() -> int:
 
 def _gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, lda=None, ldb=None, ldc=None, M=None, N=None, K=None, alpha=1.0,
           bias=None, act=_lib.ACT_NONE, aux=None, res=None, ldres=None, res_scale=None, batch1=1, batch0=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
-          gather1=None, gather_a=False, gather_b=False, a_off=0, b_off=0, c_off=0, role=0) -> None:
+          gather1=None, gather_a=False, gather_b=False, a_off=0, b_off=0, c_off=0, role=0, trans_ab=False) -> None:
     """Thin positional wrapper over tribe_gemm_bf16 (element offsets allow strided views without copies)."""
     d = GemmDesc()
+    d.trans_ab = int(trans_ab)
     d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, batch1, batch0
     d.A, d.lda, d.sA1, d.sA0 = a.data_ptr() + 2 * a_off, lda, sA[0], sA[1]
     d.B, d.ldb, d.sB1, d.sB0 = b.data_ptr() + 2 * b_off, ldb, sB[0], sB[1]
@@ -58,6 +60,19 @@ def transpose_bf16(x: torch.Tensor, Z: int, R: int, Cc: int, s_z: int, s_r: int,
     check(lib().tribe_transpose_bf16(x.data_ptr() + x.element_size() * off, _DT[x.dtype], Z, R, Cc, s_z, s_r, out.data_ptr(), Cc * R_pad, R_pad,
                                      _s()), "tribe_transpose_bf16")
     return out
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, M: int, N: int, K: int, ld_dy: int, ld_x: int) -> None:
+    """dw[n, k] = sum_m dy[m, n] x[m, k]  (dy bf16 [M, ld_dy >= N], x bf16 [M, ld_x >= K], dw f32 [N, K]): the weight gradient of a Linear.
+    Shapes the 256^2 kernel covers go through its transposed-operand form (desc.trans_ab: dy and x are read as they lie, the LDS reads
+    transpose); the rest keep the two explicit bf16 transposes in front of the NT GEMM."""
+    if M % 64 == 0 and N % 8 == 0 and K % 8 == 0 and N >= 128 and K >= 128 and ld_dy % 8 == 0 and ld_x % 8 == 0:
+        _gemm(dy, x, dw, lda=ld_dy, ldb=ld_x, ldc=K, M=N, N=K, K=M, trans_ab=True)
+        return
+    dy_t = transpose_bf16(dy, 1, M, N, 0, ld_dy)[0]   # [N, M_pad]
+    x_t = transpose_bf16(x, 1, M, K, 0, ld_x)[0]      # [K, M_pad]
+    Mp = dy_t.shape[1]
+    _gemm(dy_t, x_t, dw, lda=Mp, ldb=Mp, ldc=K, M=N, N=K, K=Mp)
 
 
 def colsum(a: torch.Tensor, M: int, N: int, b: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -139,11 +154,8 @@ class Linear(torch.autograd.Function):
         dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
         _gemm(dpre, wt, dx, lda=Np, ldb=Np, ldc=K, M=M, N=K, K=Np)
         # dW[n, k] = sum_m dpre[m, n] x[m, k]
-        dpre_t = transpose_bf16(dpre, 1, M, N, 0, Np)[0]  # [N, M_pad]
-        x_t = transpose_bf16(x, 1, M, K, 0, K)[0]         # [K, M_pad]
-        Mp = dpre_t.shape[1]
         dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
-        _gemm(dpre_t, x_t, dw, lda=Mp, ldb=Mp, ldc=K, M=N, N=K, K=Mp)
+        wgrad(dpre, x, dw, M, N, K, Np, K)
         dw = dw[:, : w.shape[1]] if w.shape[1] != K else dw
         db = colsum(dpre, M, N) if ctx.has_b else None
         if Np != N and db is not None:
@@ -207,11 +219,8 @@ class QKVLinear(torch.autograd.Function):
             dpre = torch.nn.functional.pad(dpre, (0, Np - N3))
         dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
         _gemm(dpre, wt, dx, lda=Np, ldb=Np, ldc=K, M=M, N=K, K=Np)
-        dpre_t = transpose_bf16(dpre, 1, M, N3, 0, Np)[0]       # [3N, M_pad]
-        x_t = transpose_bf16(x, 1, M, K, 0, K)[0]               # [K, M_pad]
-        Mp = dpre_t.shape[1]
         dw = torch.empty(N3, K, dtype=torch.float32, device=x.device)
-        _gemm(dpre_t, x_t, dw, lda=Mp, ldb=Mp, ldc=K, M=N3, N=K, K=Mp)
+        wgrad(dpre, x, dw, M, N3, K, Np, K)
         return dx, dw[:N], dw[N:2 * N], dw[2 * N:]
 
 
@@ -247,19 +256,14 @@ class FeedForward(torch.autograd.Function):
         _, w2t = PACKS.get(w2)                                  # [Fh, D]
         dpre = torch.empty(M, Fh, dtype=torch.bfloat16, device=x.device)
         _gemm(dob, w2t, dpre, lda=D, ldb=D, ldc=Fh, M=M, N=Fh, K=D, act=_lib.ACT_GELU_BWD, aux=pre)   # dh * gelu'(pre)
-        dob_t = transpose_bf16(dob, 1, M, D, 0, D)[0]           # [D, Mp]
-        h_t = transpose_bf16(h, 1, M, Fh, 0, Fh)[0]             # [Fh, Mp]
-        Mp = dob_t.shape[1]
         dw2 = torch.empty(D, Fh, dtype=torch.float32, device=x.device)
-        _gemm(dob_t, h_t, dw2, lda=Mp, ldb=Mp, ldc=Fh, M=D, N=Fh, K=Mp)
+        wgrad(dob, h, dw2, M, D, Fh, D, Fh)
         db1 = colsum(dpre, M, Fh)
         _, w1t = PACKS.get(w1)                                  # [D, Fh]
         dx = torch.empty(M, D, dtype=torch.float32, device=x.device)
         _gemm(dpre, w1t, dx, lda=Fh, ldb=Fh, ldc=D, M=M, N=D, K=Fh)
-        dpre_t = transpose_bf16(dpre, 1, M, Fh, 0, Fh)[0]       # [Fh, Mp]
-        x_t = transpose_bf16(x, 1, M, D, 0, D)[0]               # [D, Mp]
         dw1 = torch.empty(Fh, D, dtype=torch.float32, device=x.device)
-        _gemm(dpre_t, x_t, dw1, lda=Mp, ldb=Mp, ldc=D, M=Fh, N=D, K=Mp)
+        wgrad(dpre, x, dw1, M, Fh, D, Fh, D)
         return dx, dw1, db1, dw2, db2, dres, drs
 
 
@@ -553,11 +557,8 @@ class ProjectorFuse(torch.autograd.Function):
         N, K = w.shape
         dy = dy.contiguous()
         dyb = cast_bf16(dy)
-        dy_t = transpose_bf16(dyb, 1, M, N, 0, N)[0]
-        f_t = transpose_bf16(feat, 1, M, Kp, 0, Kp)[0]
-        Mp = dy_t.shape[1]
         dw = torch.empty(N, Kp, dtype=torch.float32, device=feat.device)
-        _gemm(dy_t, f_t, dw, lda=Mp, ldb=Mp, ldc=Kp, M=N, N=Kp, K=Mp)
+        wgrad(dyb, feat, dw, M, N, Kp, N, Kp)
         return None, dw[:, :K].contiguous() if Kp != K else dw, colsum(dy, M, N)
 
 

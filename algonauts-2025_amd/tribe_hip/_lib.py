@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
         ("rowadd", vp), ("ld_rowadd", i64), ("rowadd_period", i64),
         ("gadd", vp), ("gadd_index", vp), ("gadd_div", i64), ("ld_gadd", i64),
         ("aux", vp), ("ld_aux", i64), ("gather_b", i32),
-        ("role", i32), ("tile_hint", i32),
+        ("role", i32), ("tile_hint", i32), ("trans_ab", i32),
         ("c_bf16", vp), ("ld_c_bf16", i64), ("row_sumsq", vp), ("ld_row_sumsq", i64), ("row_scale", vp),
     ]
 

@@ -109,6 +109,27 @@ def gemm_nt(
     return out
 
 
+def gemm_tn(at: torch.Tensor, bt: torch.Tensor, *, out_dtype: torch.dtype = torch.float32, alpha: float = 1.0,
+            bias: torch.Tensor | None = None) -> torch.Tensor:
+    """out[m, n] = alpha * sum_k at[k, m] * bt[k, n] (+ bias[n]); at bf16 [K, M], bt bf16 [K, N], K % 64 == 0, M and N multiples of 8
+    (tribe_gemm_desc.trans_ab: the weight-gradient form dW = dY^T X without explicit transposes)."""
+    _cuda(at, torch.bfloat16, "at")
+    _cuda(bt, torch.bfloat16, "bt")
+    if at.ndim != 2 or bt.ndim != 2 or at.shape[0] != bt.shape[0]:
+        raise ValueError(f"gemm_tn: incompatible shapes {tuple(at.shape)} x {tuple(bt.shape)}")
+    K, M = at.shape
+    N = bt.shape[1]
+    out = torch.empty(M, N, dtype=out_dtype, device=at.device)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, 1, 1
+    d.A, d.lda, d.B, d.ldb = at.data_ptr(), M, bt.data_ptr(), N
+    d.C, d.ldc, d.c_dtype, d.alpha, d.trans_ab = out.data_ptr(), N, _DT[out_dtype], alpha, 1
+    if bias is not None:
+        d.bias, d.bias_mode = _cuda(bias, torch.float32, "bias").data_ptr(), _lib.BIAS_COL
+    check(lib().tribe_gemm_bf16(C.byref(d), _stream()), "tribe_gemm_bf16")
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # packing
 # --------------------------------------------------------------------------------------

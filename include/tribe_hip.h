@@ -84,6 +84,10 @@ typedef struct tribe_gemm_desc {
   int32_t gather_b;        /* gather1 also replaces b1 for the B operand */
   int32_t role;            /* enum tribe_gemm_role */
   int32_t tile_hint;       /* 0 = automatic, 1 = force 128x128 tiles, 2 = force 256x256 tiles (tests / tuning) */
+  /* 1 = the operands are given TRANSPOSED: A is At [K, M] (lda >= M), B is Bt [K, N] (ldb >= N), C[m][n] = sum_k At[k][m] Bt[k][n] --
+   * the weight gradient dW = dY^T X straight from the row-major dY [tokens, N_out] and X [tokens, K_in] the forward produced, without
+   * the explicit transposes (torch.nn.functional.linear's backward in the reference).  M, N multiples of 8; plain epilogue only. */
+  int32_t trans_ab;
   /* ScaleNorm folded into the GEMMs either side of it (x_transformers pre-norm: y = W . (x * s_m), s_m = g sqrt(d) / |x_m|):
    * the PRODUCER of x (f32 C) also emits a bf16 copy and per-row partial sums of squares, one slot per 64 output columns
    * (row_sumsq[m * ld_row_sumsq + n / 64]); tribe_rownorm_scale_fwd turns them into s_m; the CONSUMER multiplies its

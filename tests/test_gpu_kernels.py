@@ -247,6 +247,22 @@ def test_attention(ops, B, T, h, d, mode):
     torch.testing.assert_close(out, want, rtol=2**-6, atol=3e-3)
 
 
+# Transposed-operand GEMM (tribe_gemm_desc.trans_ab): C = At^T Bt, the weight-gradient form.  Whole tiles, ragged M / N (multiples of 8
+# only), one K-tile, a long reduction, bf16 output + bias.
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 1024), (3072, 1024, 4096), (264, 520, 128), (8, 16, 64), (1000, 296, 192)])
+def test_gemm_transposed_operands(ops, M, N, K):
+    g = torch.Generator().manual_seed(12)
+    at, bt = bf(torch.randn(K, M, generator=g)), bf(torch.randn(K, N, generator=g))
+    bias = torch.randn(N, generator=g)
+    want = at.t() @ bt
+    got = ops.gemm_tn(_dev(at).bfloat16(), _dev(bt).bfloat16()).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-3 * K**0.5)
+    got = ops.gemm_tn(_dev(at).bfloat16(), _dev(bt).bfloat16(), out_dtype=torch.bfloat16, alpha=0.5, bias=_dev(bias)).float().cpu()
+    torch.testing.assert_close(got, bf(0.5 * want + bias), rtol=2**-7, atol=2e-2 * K**0.5)
+    with pytest.raises(ValueError, match="multiples of 8"):
+        ops.gemm_tn(_dev(at[:, : M - 3].contiguous()).bfloat16(), _dev(bt).bfloat16())   # M not a multiple of 8
+
+
 # dim_head 64 (the extractors) on the 64-row-per-wave kernels (mode 4: four waves; mode 5: anti-phase wave pairs; mode 0 picks by
 # grid size) and on the 16-row kernel (mode 2): several query blocks, ragged last key tile and last row tile, one sub-tile only
 # (T = 20), an odd number of sub-tiles (T = 1000: 32 sub-tiles, T = 3000: 94, T = 257: 9), a late deferred-max rescale.
