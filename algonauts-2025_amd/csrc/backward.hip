@@ -97,6 +97,55 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, co
   if (m0 < m1) atomicAdd(out + n, acc);
 }
 
+// the same sums, four columns per lane (16-byte f32 / 8-byte bf16 loads, read once: nontemporal) and eight rows in flight per lane: the
+// one-column kernel above kept one 4-byte load per lane in flight and ran at 2.0-2.4 TB/s (bias gradients: 3.9 ms of the B = 16 step)
+template <typename T>
+__device__ __forceinline__ float4 ld4f(const T* p);
+template <>
+__device__ __forceinline__ float4 ld4f<float>(const float* p) { return load_nt_f4(p); }
+template <>
+__device__ __forceinline__ float4 ld4f<unsigned short>(const unsigned short* p) {
+  const u16x4_t v = __builtin_nontemporal_load((const u16x4_t*)p);
+  return make_float4(bf16_to_f32(v[0]), bf16_to_f32(v[1]), bf16_to_f32(v[2]), bf16_to_f32(v[3]));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colsum4_kernel(const T* __restrict__ a, const float* __restrict__ b, int64_t M, int64_t N, int64_t ld,
+                                                      float* __restrict__ out) {
+  constexpr int U = 8;
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (n >= N) return;
+  const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+  const int64_t m0 = (int64_t)blockIdx.y * per, m1 = (m0 + per < M) ? m0 + per : M;
+  float4 acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t m = m0;
+  for (; m + U <= m1; m += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ld4f<T>(a + (m + u) * ld + n);
+    if (b) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float4 w = load_nt_f4(b + (m + u) * ld + n);
+        v[u].x *= w.x; v[u].y *= w.y; v[u].z *= w.z; v[u].w *= w.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
+  }
+  for (; m < m1; ++m) {
+    float4 v = ld4f<T>(a + m * ld + n);
+    if (b) { const float4 w = load_nt_f4(b + m * ld + n); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+    acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+  }
+#pragma unroll
+  for (int u = 1; u < U; ++u) { acc[0].x += acc[u].x; acc[0].y += acc[u].y; acc[0].z += acc[u].z; acc[0].w += acc[u].w; }
+  if (m0 < m1) {
+    atomicAdd(out + n, acc[0].x); atomicAdd(out + n + 1, acc[0].y); atomicAdd(out + n + 2, acc[0].z); atomicAdd(out + n + 3, acc[0].w);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scalenorm_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                             const float* __restrict__ g, float gain_scale, float eps, int64_t rows,
@@ -460,6 +509,20 @@ extern "C" int tribe_colsum_fwd(const void* a, int32_t a_dtype, const float* b, 
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
     if (e != hipSuccess) { tribe_set_error("tribe_colsum_fwd: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  const int esz = a_dtype == TRIBE_F32 ? 4 : 2;
+  if ((a_dtype == TRIBE_F32 || a_dtype == TRIBE_BF16) && N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)a % (4 * esz)) == 0 && (!b || ((uintptr_t)b % 16) == 0)) {
+    // enough row slices for several waves per SIMD, but at least 32 rows per lane so that the 8-deep loop is what runs
+    const int64_t col_blocks = (N / 4 + 255) / 256;
+    int64_t slices4 = (8192 + col_blocks - 1) / col_blocks;
+    if (slices4 > (M + 127) / 128) slices4 = (M + 127) / 128;   // >= 128 rows per lane: the atomics on the N sums are serialised per address
+    if (slices4 < 1) slices4 = 1;
+    if (slices4 > 65535) slices4 = 65535;
+    dim3 grid4((unsigned)col_blocks, (unsigned)slices4);
+    if (a_dtype == TRIBE_F32) hipLaunchKernelGGL(colsum4_kernel<float>, grid4, dim3(256), 0, s, (const float*)a, b, M, N, ld, out);
+    else hipLaunchKernelGGL(colsum4_kernel<unsigned short>, grid4, dim3(256), 0, s, (const unsigned short*)a, b, M, N, ld, out);
+    TRIBE_LAUNCH_CHECK();
+    return 0;
   }
   int64_t slices = (M + 127) / 128;
   if (slices > 256) slices = 256;

@@ -104,6 +104,20 @@ def test_subject_head_gradients_with_repeated_subjects(V):
     assert torch.equal(grads[0][1], grads[1][1])
 
 
+@pytest.mark.parametrize("M,N,dtype,with_b", [(16384, 3072, torch.float32, False), (4099, 768, torch.float32, True), (1000, 12288, torch.bfloat16, False),
+                                              (77, 1001, torch.float32, True), (5, 8, torch.bfloat16, False)])
+def test_column_sums(M, N, dtype, with_b):
+    """tribe_colsum_fwd (bias gradients, res_scale gradients): the four-columns-per-lane kernel and, for N % 4 != 0, the scalar one."""
+    from modeling_utils.autograd import colsum
+
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn(M, N, generator=g).to(dtype)
+    b = torch.randn(M, N, generator=g) if with_b else None
+    want = (a.double() * (b.double() if with_b else 1.0)).sum(0)
+    got = colsum(a.cuda(), M, N, b=b.cuda() if with_b else None).cpu().double()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-3 * M**0.5)
+
+
 def test_slab_scatter_sum_is_the_ordered_sum():
     """tribe_slab_scatter_sum: dst[idx[b]] += src[b] for b in order == the same loop on the host, bit for bit."""
     from tribe_hip._lib import check, lib
