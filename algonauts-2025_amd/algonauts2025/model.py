@@ -239,14 +239,15 @@ class FmriEncoder(nn.Module):
         for i in range(enc.depth):
             norms_a, attn, res_a = enc.layers[2 * i]
             norms_f, ff, res_f = enc.layers[2 * i + 1]
-            xn = ag.ScaleNorm.apply(x, norms_a[0].g, gs, eps)
+            # the block input forks into norm(x) and the scaled residual; ScaleNormFork's backward sums the two gradients in its own kernel
+            xn, xr = ag.ScaleNormFork.apply(x, norms_a[0].g, gs, eps, res_a.residual_scale)
             qkv = ag.QKVLinear.apply(xn, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
             if enc.rotary_emb_dim:
                 qkv = ag.Rotary.apply(qkv, cos, sin, T, enc.heads, enc.dim_head, enc.rotary_emb_dim, enc.rotary_interleaved)
             ao = ag.Attention.apply(qkv, B, T, enc.heads, enc.dim_head, scale)
-            x = ag.Linear.apply(ao, attn.to_out.weight, None, x, res_a.residual_scale, True)
-            xn = ag.ScaleNorm.apply(x, norms_f[0].g, gs, eps)
-            x = ag.FeedForward.apply(xn, ff.ff[0][0].weight, ff.ff[0][0].bias, ff.ff[2].weight, ff.ff[2].bias, x, res_f.residual_scale)
+            x = ag.Linear.apply(ao, attn.to_out.weight, None, xr, res_a.residual_scale, True, True)
+            xn, xr = ag.ScaleNormFork.apply(x, norms_f[0].g, gs, eps, res_f.residual_scale)
+            x = ag.FeedForward.apply(xn, ff.ff[0][0].weight, ff.ff[0][0].bias, ff.ff[2].weight, ff.ff[2].bias, xr, res_f.residual_scale, True)
         return x, B, T
 
     def _forward_autograd(self, data: dict[str, torch.Tensor], pool_outputs: bool) -> torch.Tensor:

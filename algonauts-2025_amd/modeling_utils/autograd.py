@@ -121,7 +121,8 @@ class Linear(torch.autograd.Function):
     """y = x W^T + b (+ res * res_scale).  x bf16 [M, K]; W f32 [N, K]; y bf16 or f32 [M, N]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, res_scale, out_f32: bool):
+    def forward(ctx, x, w, b, res, res_scale, out_f32: bool, raw_res_grad: bool = False):
+        ctx.raw_res_grad = raw_res_grad   # the residual came from ScaleNormFork, which applies res_scale to its gradient itself
         M, K = x.shape
         N = w.shape[0]
         wp, _ = PACKS.get(w)
@@ -142,8 +143,11 @@ class Linear(torch.autograd.Function):
         dy = dy.contiguous()
         dres = drs = None
         if res is not None:
-            dres = torch.empty_like(res)
-            check(lib().tribe_scale_cols_fwd(dy.data_ptr(), ops._p(res_scale), M, N, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
+            if ctx.raw_res_grad:
+                dres = dy
+            else:
+                dres = torch.empty_like(res)
+                check(lib().tribe_scale_cols_fwd(dy.data_ptr(), ops._p(res_scale), M, N, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
             if res_scale is not None:
                 drs = colsum(dy, M, N, b=res)
         _, wt = PACKS.get(w)  # [K, N_pad64]
@@ -160,7 +164,7 @@ class Linear(torch.autograd.Function):
         db = colsum(dpre, M, N) if ctx.has_b else None
         if Np != N and db is not None:
             db = db[:N]
-        return dx, dw, db, dres, drs, None
+        return dx, dw, db, dres, drs, None, None
 
 
 class _FusedQKVPacks:
@@ -229,7 +233,8 @@ class FeedForward(torch.autograd.Function):
     x bf16 [M, D]; res f32 [M, D] (the block input); out f32 [M, D]."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, res, res_scale):
+    def forward(ctx, x, w1, b1, w2, b2, res, res_scale, raw_res_grad: bool = False):
+        ctx.raw_res_grad = raw_res_grad   # see Linear
         M, D = x.shape
         Fh = w1.shape[0]
         w1p, _ = PACKS.get(w1)
@@ -248,8 +253,11 @@ class FeedForward(torch.autograd.Function):
         M, D = x.shape
         Fh = w1.shape[0]
         dout = dout.contiguous()
-        dres = torch.empty_like(res)
-        check(lib().tribe_scale_cols_fwd(dout.data_ptr(), ops._p(res_scale), M, D, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
+        if ctx.raw_res_grad:
+            dres = dout
+        else:
+            dres = torch.empty_like(res)
+            check(lib().tribe_scale_cols_fwd(dout.data_ptr(), ops._p(res_scale), M, D, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
         drs = colsum(dout, M, D, b=res) if res_scale is not None else None
         db2 = colsum(dout, M, D)
         dob = cast_bf16(dout)                                   # [M, D]
@@ -264,7 +272,7 @@ class FeedForward(torch.autograd.Function):
         _gemm(dpre, w1t, dx, lda=Fh, ldb=Fh, ldc=D, M=M, N=D, K=Fh)
         dw1 = torch.empty(Fh, D, dtype=torch.float32, device=x.device)
         wgrad(dpre, x, dw1, M, Fh, D, Fh, D)
-        return dx, dw1, db1, dw2, db2, dres, drs
+        return dx, dw1, db1, dw2, db2, dres, drs, None
 
 
 class ScaleNorm(torch.autograd.Function):
@@ -286,6 +294,35 @@ class ScaleNorm(torch.autograd.Function):
         dg = torch.zeros(1, dtype=torch.float32, device=x.device)
         check(lib().tribe_scalenorm_bwd(x.data_ptr(), dy.data_ptr(), _DT[dy.dtype], g.data_ptr(), ctx.gs, ctx.eps, M, D, None, None,
                                         dx.data_ptr(), dg.data_ptr(), _s()), "tribe_scalenorm_bwd")
+        return dx, dg, None, None, None
+
+
+class ScaleNormFork(torch.autograd.Function):
+    """(xn, xr) = (ScaleNorm(x), x): the input of a pre-norm block forked into its normed branch and its residual branch (x_transformers
+    `Residual(scale_residual=True)`: block(norm(x)) + x * res_scale).  The backward adds the two incoming gradients INSIDE the ScaleNorm
+    backward kernel, dx = d_norm + d_res * res_scale: the consumer of `xr` (Linear / FeedForward with raw_res_grad=True) hands its output
+    gradient back as it is, so the per-block column scaling pass and autograd's add of the two branches (two f32 [M, D] passes each) go."""
+
+    @staticmethod
+    def forward(ctx, x, g, gain_scale: float, eps: float, res_scale):
+        y = ops.scalenorm(x, g, gain_scale, eps, torch.bfloat16)
+        ctx.save_for_backward(x, g, res_scale)
+        ctx.gs, ctx.eps = gain_scale, eps
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dxr):
+        x, g, rs = ctx.saved_tensors
+        M, D = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.zeros(1, dtype=torch.float32, device=x.device)
+        if dy is None:    # the normed branch was not used: only the residual gradient flows
+            dx = dxr if rs is None else dxr * rs
+            return dx, None, None, None, None
+        dy = dy.contiguous()
+        dres = None if dxr is None else dxr.float().contiguous()
+        check(lib().tribe_scalenorm_bwd(x.data_ptr(), dy.data_ptr(), _DT[dy.dtype], g.data_ptr(), ctx.gs, ctx.eps, M, D, ops._p(dres),
+                                        None if dres is None else ops._p(rs), dx.data_ptr(), dg.data_ptr(), _s()), "tribe_scalenorm_bwd")
         return dx, dg, None, None, None
 
 

@@ -79,6 +79,25 @@ def test_autograd_blocks_vs_torch():
     torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=1e-5, atol=1e-7)
 
 
+def test_scalenorm_fork_sums_both_branches_in_its_backward():
+    """ScaleNormFork + a residual consumer with raw_res_grad=True == the plain pre-norm residual block y = Linear(norm(x)) + x * rs."""
+    from modeling_utils import autograd as ag
+
+    g = torch.Generator().manual_seed(9)
+    M, D = 70, 768
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = torch.randn(M, D, generator=g); gpar = torch.tensor([1.1]); rs = torch.rand(D, generator=g) + 0.5
+    w = bf(torch.randn(D, D, generator=g) / D**0.5); dy = torch.randn(M, D, generator=g)
+    xt, gt, rst, wt = (t.clone().requires_grad_() for t in (x, gpar, rs, w))
+    xn = xt / xt.norm(dim=-1, keepdim=True).clamp(min=1e-12) * D**0.5 * gt
+    (xn.to(torch.bfloat16).float() @ wt.t() + xt * rst).backward(dy)
+    xg, gg, rsg, wg = (t.cuda().requires_grad_() for t in (x, gpar, rs, w))
+    yn, xr = ag.ScaleNormFork.apply(xg, gg, D**0.5, 1e-12, rsg)
+    ag.Linear.apply(yn, wg, None, xr, rsg, True, True).backward(dy.cuda())
+    for name, got, want in (("dx", xg.grad, xt.grad), ("dg", gg.grad, gt.grad), ("drs", rsg.grad, rst.grad), ("dw", wg.grad, wt.grad)):
+        assert _rel(got.cpu(), want) < 2e-2, name
+
+
 @pytest.mark.parametrize("V", [20, 23])   # C * V % 4 == 0: one batched GEMM + ordered device scatter sum; otherwise the per-sample chain
 def test_subject_head_gradients_with_repeated_subjects(V):
     """SubjectLayers (modeling_utils/models/common.py:60-76 in the reference) backward when several samples share a subject: dW[s] is
