@@ -38,6 +38,10 @@ def test_extractor_building_blocks():
     got = ops.segment_mean(seq.cuda(), 3, 7, start.cuda(), length.cuda()).cpu()
     want = torch.stack([seq.view(3, 7, 64)[i, s:s + n].mean(0) for i, (s, n) in enumerate(zip(start.tolist(), length.tolist()))])
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    # whole-sequence means of a ViT-sized state (the 8-rows-in-flight loop, several row slices) and a width that is not a multiple of 4
+    for T_, dim_ in ((2000, 1408), (333, 1408), (50, 30)):
+        big = torch.randn(2 * T_, dim_, generator=g)
+        torch.testing.assert_close(ops.segment_mean(big.cuda(), 2, T_, None, None).cpu(), big.view(2, T_, dim_).mean(1), rtol=1e-4, atol=1e-5)
     # SwiGLU epilogue: out[:, j] = silu(v[:, 2j]) * v[:, 2j+1]
     a, wgu = bf(torch.randn(70, 128, generator=g)), bf(torch.randn(2 * 96, 128, generator=g) / 11)
     v = a @ wgu.t()
