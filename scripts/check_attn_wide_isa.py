@@ -1,4 +1,4 @@
-"""Audit of the DH = 384 attention kernel's ISA (run after every edit of attention.hip; CPU only, needs hipcc):
+"""Audit of the attention and GEMM kernels' ISA (run after every edit of attention*.hip / gemm.hip; CPU only, needs hipcc).  DH = 384:
   * no scratch (a spilled Q fragment reloads every tile),
   * no compiler-generated v_accvgpr_* or MFMA outside the ASMSTART / ASMEND blocks (a0..a191 hold O^T and belong to the asm
     statements of attn_acc_regs.h; the compiler must not allocate accumulator registers of its own),
@@ -42,6 +42,33 @@ def audit(kernel: str, max_regs: int) -> bool:
 
 
 ok = audit("attn_fwd_wide384", 512) & audit("attn_fwd_ksplit384", 256)
+
+# The DH = 64 kernels (attention_d64.hip) and the two forms of the 256^2 GEMM use compiler-allocated registers throughout; what must hold
+# is the budget of two waves per SIMD WITHOUT scratch: a spilled accumulator or Q fragment is reloaded every key tile / K-tile.
+def no_scratch(source: str, kernels: list[str]) -> bool:
+    with tempfile.TemporaryDirectory() as tmp2:
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT / 'include'}", "-save-temps",
+                        "-c", str(CSRC / source), "-o", f"{tmp2}/x.o"], check=True, cwd=tmp2, capture_output=True)
+        isa = Path(tmp2, source.replace(".hip", "-hip-amdgcn-amd-amdhsa-gfx950.s")).read_text()
+    good = True
+    for kernel in kernels:
+        found = re.findall(rf"\.amdhsa_kernel (_ZN\S*{kernel}\S*)\n(.*?)\.end_amdhsa_kernel", isa, re.S)
+        if not found:
+            print(f"FAIL: kernel {kernel} not found in the ISA of {source}")
+            good = False
+        for name, body in found:
+            meta = {k: int(v) for k, v in re.findall(r"\.amdhsa_(next_free_vgpr|private_segment_fixed_size)\s+(\d+)", body)}
+            line = f"{kernel} [{name[-40:]}]: {meta}"
+            if meta.get("private_segment_fixed_size", 1) or meta.get("next_free_vgpr", 9999) > 256:
+                print("FAIL (scratch or more than 256 registers):", line)
+                good = False
+            else:
+                print(line)
+    return good
+
+
+ok &= no_scratch("attention_d64.hip", ["attn_fwd_d64_kernel", "attn_fwd_d64_pair_kernel"])
+ok &= no_scratch("gemm.hip", ["gemm_nt_256x256x64"])
 if not ok:
     sys.exit(1)
 print("OK: no scratch, no compiler accumulator-register traffic")
