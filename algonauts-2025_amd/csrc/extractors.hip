@@ -49,7 +49,9 @@ struct Fp8Linear4 {
   float w_scale[4];
   float in_scale[4];
 };
-static_assert(sizeof(Fp8Linear4) == sizeof(tribe_llama_fp8_layer) && sizeof(Fp8Linear4) == sizeof(tribe_vit_fp8_layer), "fp8 layer layouts");
+static_assert(sizeof(Fp8Linear4) == sizeof(tribe_llama_fp8_layer) && sizeof(Fp8Linear4) == sizeof(tribe_vit_fp8_layer) &&
+                  sizeof(Fp8Linear4) == sizeof(tribe_conformer_fp8_layer),
+              "fp8 layer layouts");
 
 // fp8 route of the pre-norms: the norm writes the e4m3 operand of the Linear that follows straight into the staging buffer (one pass
 // over x instead of norm -> bf16 -> quantise).  *done tells the caller whether it did; otherwise the bf16 norm must run.
@@ -82,7 +84,7 @@ inline int extractor_linear(const char* who, const void* fp8_layers, float* amax
   }
   g.A = q8;
   g.B = F.w[which];
-  g.alpha = F.in_scale[which] * F.w_scale[which];
+  g.alpha *= F.in_scale[which] * F.w_scale[which];   // on top of the caller's alpha (Conformer half-step FFN: 0.5)
   return tribe_gemm_fp8(&g, stream);
 }
 }  // namespace
@@ -317,7 +319,7 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
 namespace {
 struct W2vPlan {
   int64_t M, qe_ld;
-  size_t x_b, xn_b, wide_b, qe_b, ao_b, glu_b, feat_b, featp_b;
+  size_t x_b, xn_b, wide_b, qe_b, ao_b, glu_b, feat_b, featp_b, q8_b;
 };
 inline W2vPlan w2v_plan(const tribe_w2vbert_desc* d) {
   W2vPlan p;
@@ -328,6 +330,7 @@ inline W2vPlan w2v_plan(const tribe_w2vbert_desc* d) {
   p.xn_b = align256((size_t)p.M * d->dim * 2);
   const int64_t wide = d->inter > 3 * d->dim ? d->inter : 3 * d->dim;
   p.wide_b = align256((size_t)p.M * wide * 2);
+  p.q8_b = d->fp8_host ? align256((size_t)p.M * (d->inter > d->dim ? d->inter : d->dim)) : 0;   // e4m3 staging of one GEMM input
   p.qe_b = align256((size_t)p.M * p.qe_ld * 4);
   p.ao_b = align256((size_t)p.M * d->dim * 2);
   p.glu_b = align256((size_t)p.M * d->dim * 2);
@@ -340,7 +343,7 @@ inline W2vPlan w2v_plan(const tribe_w2vbert_desc* d) {
 extern "C" size_t tribe_w2vbert_workspace_bytes(const tribe_w2vbert_desc* d) {
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   const W2vPlan p = w2v_plan(d);
-  return p.x_b + p.xn_b + p.wide_b + p.qe_b + p.ao_b + p.glu_b + p.feat_b + p.featp_b;
+  return p.x_b + p.xn_b + p.wide_b + p.qe_b + p.ao_b + p.glu_b + p.feat_b + p.featp_b + p.q8_b;
 }
 
 extern "C" int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, void* workspace, size_t workspace_bytes, void* stream) {
@@ -362,7 +365,10 @@ extern "C" int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, voi
   uint16_t* ao = (uint16_t*)w; w += p.ao_b;
   uint16_t* glu = (uint16_t*)w; w += p.glu_b;
   float* feat = (float*)w; w += p.feat_b;
-  uint16_t* featp = (uint16_t*)w;
+  uint16_t* featp = (uint16_t*)w; w += p.featp_b;
+  uint8_t* q8 = (uint8_t*)w;
+  TRIBE_REQUIRE(!d->fp8_host || (d->dim % 128 == 0 && d->inter % 128 == 0), "tribe_w2vbert_fwd: the fp8 path needs dim and inter to be multiples of 128");
+  TRIBE_REQUIRE(!(d->fp8_host && d->amax_out), "tribe_w2vbert_fwd: calibrate (amax_out) on the bf16 path, not together with fp8_host");
   const int64_t M = p.M, dim = d->dim;
   const int64_t state_sz = d->B * d->n_out * dim;
   const int npos = d->rel_left + d->rel_right + 1;
@@ -383,23 +389,27 @@ extern "C" int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, voi
   rc = tribe_gather_rows_fwd(x, d->B, d->T, dim, d->out_index, d->n_out, states, stream);
   if (rc) return rc;
 
-  auto ffn = [&](const float* ln_w, const float* ln_b, const uint16_t* w_in, const float* b_in, const uint16_t* w_out,
+  // half-step feed-forward x += 0.5 * (swish(LN(x) W_in^T + b_in) W_out^T + b_out); `which` = 0 (ffn1) or 2 (ffn2) selects the pair of e4m3
+  // weights / scales of the layer when fp8_host is set (the LayerNorm then writes the e4m3 operand directly)
+  auto ffn = [&](int l, int which, const float* ln_w, const float* ln_b, const uint16_t* w_in, const float* b_in, const uint16_t* w_out,
                  const float* b_out_half) -> int {
-    int r = tribe_layernorm_fwd(x, M, dim, ln_w, ln_b, d->ln_eps, xn, TRIBE_BF16, stream);
+    bool q_in = false;
+    int r = extractor_norm_fp8(d->fp8_host, l, which, x, M, dim, ln_w, ln_b, 1, d->ln_eps, q8, stream, &q_in);
+    if (!r && !q_in) r = tribe_layernorm_fwd(x, M, dim, ln_w, ln_b, d->ln_eps, xn, TRIBE_BF16, stream);
     if (r) return r;
     tribe_gemm_desc q = gemm_zero();
     q.M = M; q.N = d->inter; q.K = dim;
-    q.A = xn; q.lda = dim; q.B = w_in; q.ldb = dim;
+    q.A = xn; q.lda = dim; q.ldb = dim;
     q.C = wide; q.ldc = d->inter; q.c_dtype = TRIBE_BF16; q.act = TRIBE_ACT_SILU; q.role = TRIBE_ROLE_FF1;
     if (b_in) { q.bias = b_in; q.bias_mode = TRIBE_BIAS_COL; }
-    r = tribe_gemm_bf16(&q, stream);
+    r = extractor_linear("tribe_w2vbert_fwd", d->fp8_host, d->amax_out, l, which, q, w_in, q8, stream, q_in);
     if (r) return r;
     q = gemm_zero();  // x = 0.5 * (h W^T + b) + x
     q.M = M; q.N = dim; q.K = d->inter;
-    q.A = wide; q.lda = d->inter; q.B = w_out; q.ldb = d->inter;
+    q.A = wide; q.lda = d->inter; q.ldb = d->inter;
     q.C = x; q.ldc = dim; q.c_dtype = TRIBE_F32; q.alpha = 0.5f; q.res = x; q.ldres = dim; q.role = TRIBE_ROLE_FF2;
     if (b_out_half) { q.bias = b_out_half; q.bias_mode = TRIBE_BIAS_COL; }
-    return tribe_gemm_bf16(&q, stream);
+    return extractor_linear("tribe_w2vbert_fwd", d->fp8_host, d->amax_out, l, which + 1, q, w_out, q8, stream);
   };
 
   for (int l = 0; l < d->depth; ++l) {
@@ -408,7 +418,7 @@ extern "C" int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, voi
                       L.w_pw1 && L.w_dw_kc && L.dw_ln_w && L.w_pw2 && L.ffn2_ln_w && L.w_ffn2_in && L.w_ffn2_out && L.final_ln_w,
                   "tribe_w2vbert_fwd: layer %d has a null parameter", l);
     // 1. half-step feed-forward
-    rc = ffn(L.ffn1_ln_w, L.ffn1_ln_b, L.w_ffn1_in, L.b_ffn1_in, L.w_ffn1_out, L.b_ffn1_out_half);
+    rc = ffn(l, 0, L.ffn1_ln_w, L.ffn1_ln_b, L.w_ffn1_in, L.b_ffn1_in, L.w_ffn1_out, L.b_ffn1_out_half);
     if (rc) return rc;
     // 2. self-attention with relative_key bias
     rc = tribe_layernorm_fwd(x, M, dim, L.attn_ln_w, L.attn_ln_b, d->ln_eps, xn, TRIBE_BF16, stream);
@@ -462,7 +472,7 @@ extern "C" int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, voi
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     // 4. half-step feed-forward, then the block's final LayerNorm (in place on the residual stream)
-    rc = ffn(L.ffn2_ln_w, L.ffn2_ln_b, L.w_ffn2_in, L.b_ffn2_in, L.w_ffn2_out, L.b_ffn2_out_half);
+    rc = ffn(l, 2, L.ffn2_ln_w, L.ffn2_ln_b, L.w_ffn2_in, L.b_ffn2_in, L.w_ffn2_out, L.b_ffn2_out_half);
     if (rc) return rc;
     rc = tribe_layernorm_fwd(x, M, dim, L.final_ln_w, L.final_ln_b, d->ln_eps, x, TRIBE_F32, stream);
     if (rc) return rc;

@@ -65,16 +65,21 @@ class HipWav2Vec2Bert:
         self.w_fp = ops.pack_weight(f32("feature_projection.projection.weight"), cols_pad=self.feat_pad)
         self.b_fp = f32("feature_projection.projection.bias")
         self.layers = (ConformerLayer * max(self.depth, 1))()
+        self.ffn_packs: list[list[torch.Tensor]] = []     # per layer: bf16 ffn1 in / out, ffn2 in / out (what enable_fp8 quantises)
+        self.fp8_layers = None
         H = self.dim
         for i in range(self.depth):
             p = f"encoder.layers.{i}."
             L = self.layers[i]
+            self.ffn_packs.append([])
             for tag in ("ffn1", "ffn2"):
                 setattr(L, f"{tag}_ln_w", own(f32(p + f"{tag}_layer_norm.weight")))
                 setattr(L, f"{tag}_ln_b", own(f32(p + f"{tag}_layer_norm.bias")))
-                setattr(L, f"w_{tag}_in", own(ops.pack_weight(f32(p + f"{tag}.intermediate_dense.weight"))))
+                w_in, w_out = ops.pack_weight(f32(p + f"{tag}.intermediate_dense.weight")), ops.pack_weight(f32(p + f"{tag}.output_dense.weight"))
+                self.ffn_packs[-1] += [w_in, w_out]
+                setattr(L, f"w_{tag}_in", own(w_in))
                 setattr(L, f"b_{tag}_in", own(f32(p + f"{tag}.intermediate_dense.bias")))
-                setattr(L, f"w_{tag}_out", own(ops.pack_weight(f32(p + f"{tag}.output_dense.weight"))))
+                setattr(L, f"w_{tag}_out", own(w_out))
                 setattr(L, f"b_{tag}_out_half", own(0.5 * f32(p + f"{tag}.output_dense.bias")))  # x + 0.5 * ffn(x)
             L.attn_ln_w, L.attn_ln_b = own(f32(p + "self_attn_layer_norm.weight")), own(f32(p + "self_attn_layer_norm.bias"))
             a = p + "self_attn."
@@ -91,9 +96,39 @@ class HipWav2Vec2Bert:
             L.w_pw2 = own(ops.pack_weight(f32(c + "pointwise_conv2.weight").squeeze(-1)))
             L.final_ln_w, L.final_ln_b = own(f32(p + "final_layer_norm.weight")), own(f32(p + "final_layer_norm.bias"))
 
-    def hidden_states_resampled(self, input_features: torch.Tensor, n_out: int) -> torch.Tensor:
+    def enable_fp8(self, calibration_features: torch.Tensor, margin: float = 1.0) -> torch.Tensor:
+        """e4m3 feed-forward GEMMs (BASELINE config 5; the four FFN Linears are 70 % of a Conformer layer's GEMM flops), as
+        HipVJEPA2Encoder.enable_fp8: per-tensor weight scales, static input scales from one bf16 pass over `calibration_features`
+        [B, T, feat_dim].  Returns the amax table f32 [depth, 4] (ffn1 in / out, ffn2 in / out)."""
+        from tribe_hip._lib import ConformerFp8Layer
+
+        if self.dim % 128 or self.inter % 128:
+            raise ValueError("fp8 path: hidden_size and intermediate_size must be multiples of 128")
+        self.fp8_layers = None
+        amax = torch.zeros(max(self.depth, 1), 4, dtype=torch.float32, device=self.device)
+        self.hidden_states_resampled(calibration_features, 1, _amax=amax)
+        table = amax.cpu()
+        if not bool((table[: self.depth] > 0).all()):
+            raise ValueError("fp8 calibration saw an all-zero GEMM input")
+        layers = (ConformerFp8Layer * max(self.depth, 1))()
+        self.fp8_packs = []
+        for i in range(self.depth):
+            q = []
+            for j, w in enumerate(self.ffn_packs[i]):
+                w_scale = float(ops.absmax(w)) / ops.FP8_MAX
+                q.append(ops.quantize_fp8(w, w_scale, K_pad=w.shape[1]))
+                layers[i].w_scale[j] = w_scale
+                layers[i].in_scale[j] = float(table[i, j]) * margin / ops.FP8_MAX
+            layers[i].w_ffn1_in, layers[i].w_ffn1_out, layers[i].w_ffn2_in, layers[i].w_ffn2_out = (t.data_ptr() for t in q)
+            self.fp8_packs.append(q)
+        self.fp8_layers = layers
+        return table
+
+    def hidden_states_resampled(self, input_features: torch.Tensor, n_out: int, fp8: bool | None = None,
+                                _amax: torch.Tensor | None = None) -> torch.Tensor:
         """input_features f32 [B, T, feat_dim] (unpadded chunks) -> f32 [B, depth + 1, dim, n_out]: every hidden state
-        transposed to channels-first and nearest-resampled to n_out time points (audio.py:253-263, 163-171)."""
+        transposed to channels-first and nearest-resampled to n_out time points (audio.py:253-263, 163-171).
+        fp8: None = use the e4m3 feed-forward GEMMs when enable_fp8() has run."""
         feats = input_features.to(device=self.device, dtype=torch.float32).contiguous()
         B, T, Fd = feats.shape
         if Fd != self.feat_dim:
@@ -107,6 +142,13 @@ class HipWav2Vec2Bert:
         d.w_fp, d.b_fp = self.w_fp.data_ptr(), self.b_fp.data_ptr()
         d.layers_host = C.cast(self.layers, C.POINTER(ConformerLayer))
         d.features, d.out_index, d.n_out = feats.data_ptr(), idx.data_ptr(), n_out
+        use_fp8 = (self.fp8_layers is not None) if fp8 is None else fp8
+        if use_fp8 and _amax is None:
+            if self.fp8_layers is None:
+                raise ValueError("hidden_states_resampled(fp8=True) before enable_fp8()")
+            d.fp8_host = C.cast(self.fp8_layers, C.POINTER(type(self.fp8_layers[0])))
+        if _amax is not None:
+            d.amax_out = _amax.data_ptr()
         states = torch.empty(self.depth + 1, B, n_out, self.dim, dtype=torch.float32, device=self.device)
         ws = ops.workspace(lib().tribe_w2vbert_workspace_bytes(C.byref(d)), self.device, "extractor")
         check(lib().tribe_w2vbert_fwd(C.byref(d), states.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),

@@ -129,6 +129,12 @@ class ConformerLayer(C.Structure):
         "ffn2_ln_w", "ffn2_ln_b", "w_ffn2_in", "b_ffn2_in", "w_ffn2_out", "b_ffn2_out_half", "final_ln_w", "final_ln_b")]
 
 
+class ConformerFp8Layer(C.Structure):
+    """struct tribe_conformer_fp8_layer"""
+
+    _fields_ = [("w_ffn1_in", vp), ("w_ffn1_out", vp), ("w_ffn2_in", vp), ("w_ffn2_out", vp), ("w_scale", f32 * 4), ("in_scale", f32 * 4)]
+
+
 class W2vBertDesc(C.Structure):
     """struct tribe_w2vbert_desc"""
 
@@ -139,6 +145,7 @@ class W2vBertDesc(C.Structure):
         ("fp_ln_w", vp), ("fp_ln_b", vp), ("w_fp", vp), ("b_fp", vp),
         ("layers_host", C.POINTER(ConformerLayer)),
         ("features", vp), ("out_index", vp), ("n_out", i64),
+        ("fp8_host", C.POINTER(ConformerFp8Layer)), ("amax_out", vp),
     ]
 
 

@@ -301,6 +301,14 @@ typedef struct tribe_conformer_layer {
   const float* final_ln_w; const float* final_ln_b;
 } tribe_conformer_layer;
 
+/* fp8 variant of a Conformer layer's four feed-forward weights (see tribe_llama_fp8_layer): i = 0 ffn1.intermediate_dense, 1 ffn1.output_dense,
+ * 2 ffn2.intermediate_dense, 3 ffn2.output_dense -- 70 % of the layer's GEMM flops; the attention and convolution-module projections stay bf16 */
+typedef struct tribe_conformer_fp8_layer {
+  const uint8_t* w_ffn1_in; const uint8_t* w_ffn1_out; const uint8_t* w_ffn2_in; const uint8_t* w_ffn2_out;
+  float w_scale[4];
+  float in_scale[4];
+} tribe_conformer_fp8_layer;
+
 typedef struct tribe_w2vbert_desc {
   int64_t B, T;                       /* chunks x frames (no padding mask: the reference passes single unpadded chunks) */
   int32_t feat_dim, feat_pad;         /* 160, padded to a multiple of 64 */
@@ -311,6 +319,8 @@ typedef struct tribe_w2vbert_desc {
   const tribe_conformer_layer* layers_host;              /* HOST array [depth] */
   const float* features;              /* f32 [B*T, feat_dim] (output of the HF SeamlessM4T feature extractor) */
   const int64_t* out_index; int64_t n_out;               /* frame index of every output time point (nearest interpolation) */
+  const tribe_conformer_fp8_layer* fp8_host;             /* HOST array [depth] or NULL: e4m3 feed-forward GEMMs (BASELINE config 5) */
+  float* amax_out;                                       /* device f32 [depth, 4] or NULL: calibration of the bf16 path (max-accumulated) */
 } tribe_w2vbert_desc;
 
 size_t tribe_w2vbert_workspace_bytes(const tribe_w2vbert_desc* d);

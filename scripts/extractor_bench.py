@@ -144,6 +144,16 @@ def bench_w2vbert():
         dt = timed(lambda: model.hidden_states_resampled(feats, 120), n=3, warm=1)
         print(f"w2v-bert-2.0 fwd+resample  chunks={B} x {T} frames (60 s): {dt * 1e3:8.2f} ms  {B * 60 / dt:8.1f} audio-s/s  "
               f"{per_tok * B * T / dt / 1e12:7.1f} TFLOP/s", flush=True)
+    ref = model.hidden_states_resampled(feats, 120)
+    model.enable_fp8(torch.randn(1, 3000, 160, device="cuda"))              # e4m3 feed-forward GEMMs, static per-tensor scales
+    for B, T in ((1, 3000), (8, 3000)):
+        feats8 = torch.randn(B, T, 160, device="cuda")
+        dt = timed(lambda: model.hidden_states_resampled(feats8, 120), n=3, warm=1)
+        print(f"w2v-bert-2.0 fwd+resample  chunks={B} x {T} frames (60 s) fp8 FFN GEMMs: {dt * 1e3:8.2f} ms  {B * 60 / dt:8.1f} audio-s/s  "
+              f"{per_tok * B * T / dt / 1e12:7.1f} TFLOP/s", flush=True)
+    got = model.hidden_states_resampled(feats, 120)
+    err = ((got - ref).flatten(2).norm(dim=-1) / ref.flatten(2).norm(dim=-1)).mean(dim=0)
+    print("  fp8 vs bf16 hidden states, relative L2 error at layers 1 / 12 / 24:", [round(float(err[i]), 4) for i in (1, 12, 24)], flush=True)
 
 
 if __name__ == "__main__":

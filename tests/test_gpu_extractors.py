@@ -319,6 +319,40 @@ def _depth_curve(got, want):
     return [_rel(got[s], want[s]) for s in range(len(want))]
 
 
+def test_w2vbert_fp8_ffn_gemms_vs_quantisation_aware_reference():
+    """e4m3 feed-forward GEMMs of the Conformer layers (the four FFN Linears; attention and convolution projections stay bf16) vs the fp32
+    transformers model with the same quantisation emulated on the CPU (see test_llama_fp8_gemms_vs_quantisation_aware_reference for the
+    bar and its reasoning).  The half-step's 0.5 rides in the GEMM's alpha on top of the two scales."""
+    from data_utils.features.audio import HipWav2Vec2Bert
+
+    cfg, hf = _tiny_w2vbert(hidden=1024, heads=16, layers=2, inter=4096)
+    g = torch.Generator().manual_seed(7)
+    T, n_out = 300, 11
+    feats = torch.randn(2, T, 160, generator=g)
+    model = HipWav2Vec2Bert(cfg, hf.state_dict())
+    bf16 = model.hidden_states_resampled(feats, n_out).cpu()
+    table = model.enable_fp8(feats)
+    assert table.shape == (2, 4) and bool((table > 0).all())
+    got = model.hidden_states_resampled(feats, n_out).cpu()
+    assert torch.equal(model.hidden_states_resampled(feats, n_out, fp8=False).cpu(), bf16) and not torch.equal(got, bf16)
+    hooks = []
+    for i, layer in enumerate(hf.encoder.layers):
+        F = model.fp8_layers[i]
+        for j, m in enumerate((layer.ffn1.intermediate_dense, layer.ffn1.output_dense, layer.ffn2.intermediate_dense, layer.ffn2.output_dense)):
+            m.weight.data = _fake_quant(m.weight.data.bfloat16(), float(F.w_scale[j]))
+            hooks.append(m.register_forward_pre_hook(lambda mod, args, s=float(F.in_scale[j]): (_fake_quant(args[0], s),)))
+    with torch.no_grad():
+        out = hf(feats, output_hidden_states=True)
+    for h in hooks:
+        h.remove()
+    want = torch.nn.functional.interpolate(torch.stack(out.hidden_states, dim=1).flatten(0, 1).transpose(-1, -2), n_out)
+    want = want.view(2, cfg.num_hidden_layers + 1, cfg.hidden_size, n_out)
+    for s_ in range(want.shape[1]):
+        err = _rel(got[:, s_], want[:, s_])
+        assert err < 1e-1, f"state {s_}: relative L2 error vs the quantisation-aware reference {err:.2e}"
+    assert _rel(got[:, -1], bf16[:, -1]) < 1e-1     # and the e4m3 states stay within 10 % of the bf16 ones at this depth
+
+
 def test_llama_parity_at_28_layers():
     from data_utils.features.text import HipLlamaModel, word_pool_windows
 
