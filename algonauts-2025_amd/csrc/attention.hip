@@ -945,9 +945,6 @@ int launch_attn(const AttnArgs& a, int64_t B, hipStream_t s) {
 int tribe_internal_attn_d64_launch(const void* args, int64_t B, int relkey, int variant, hipStream_t s);   // attention_d64.hip
 namespace {
 
-thread_local const float* g_q_cos = nullptr;   // handed from tribe_internal_attention_fused_qrot to the launch below it (same thread)
-thread_local const float* g_q_sin = nullptr;
-thread_local int g_q_rot_dim = 0;
 int g_attn_d64_variant = 0;   // DH = 64: 0 = by grid size, 1 = 4-wave kernel, 2 = anti-phase 8-wave kernel (attention_d64.hip)
 int g_attn_wide384 = 1;   // DH = 384 variant: 1 = one wave per SIMD (32 rows x 384), 2 = key-split pairs, 0 = the 16-row kernel (tribe_attention_set_mode)
 
@@ -968,7 +965,9 @@ int tribe_internal_attention_fused_supported(int dim_head) {
   return dim_head == 64 || dim_head == 128 || dim_head == 192 || dim_head == 384;
 }
 
-extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* stream) {
+// the work behind tribe_attention_fwd_ex; q_cos / q_sin / q_rot_dim: partial rotary of Q applied by the kernel itself (nullptr: q arrives
+// rotated; only tribe_internal_attention_fused_qrot passes tables, and only where tribe_internal_attention_rotates_q holds)
+static int attention_dispatch(const tribe_attention_desc* d, const float* q_cos, const float* q_sin, int q_rot_dim, void* stream) {
   TRIBE_REQUIRE(d && d->q && d->k && d->v && d->out, "tribe_attention_fwd_ex: null pointer");
   TRIBE_REQUIRE(d->B > 0 && d->T > 0 && d->heads_q > 0 && d->heads_kv > 0 && d->heads_q % d->heads_kv == 0,
                 "tribe_attention_fwd_ex: bad shape (B=%lld T=%lld heads %d/%d)", (long long)d->B, (long long)d->T, d->heads_q, d->heads_kv);
@@ -986,7 +985,7 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
   a.qblocks = (int)((d->T + 127) / 128);
   a.n_bh = (int)(d->B * d->heads_q);
   a.qe = d->rel_qe; a.ld_qe = d->ld_rel_qe; a.qe_stride_h = d->rel_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
-  a.q_cos = g_q_cos; a.q_sin = g_q_sin; a.q_rot_dim = g_q_rot_dim;   // set only around tribe_internal_attention_fused_qrot
+  a.q_cos = q_cos; a.q_sin = q_sin; a.q_rot_dim = q_rot_dim;
   hipStream_t s = (hipStream_t)stream;
 #ifdef TRIBE_ATTN_STAMPS
   if (d->rel_qe && d->dim_head == 384) return launch_attn_dh<384>(a, d->B, d->causal, s);   // rel_qe carries the stamp buffer
@@ -1007,25 +1006,12 @@ extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* strea
   }
 }
 
+extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* stream) { return attention_dispatch(d, nullptr, nullptr, 0, stream); }
+
 // 1 when the next fused launch at this head size rotates Q itself if given the tables (the DH = 384 one-wave kernel)
 int tribe_internal_attention_rotates_q(int dim_head) { return dim_head == 384 && g_attn_wide384 == 1; }
 
-int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out, hipStream_t s);
-
-// as tribe_internal_attention_fused, with the partial rotary of Q (interleaved pairs) applied inside the kernel: q in `qkv` is NOT
-// rotated, k is.  Only valid while tribe_internal_attention_rotates_q(dim_head).
-int tribe_internal_attention_fused_qrot(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
-                                        const float* cos_tab, const float* sin_tab, int rot_dim, hipStream_t s) {
-  TRIBE_REQUIRE(tribe_internal_attention_rotates_q(dim_head) && cos_tab && sin_tab && rot_dim > 0 && rot_dim % 16 == 0 && rot_dim <= dim_head,
-                "tribe_internal_attention_fused_qrot: unsupported configuration");
-  g_q_cos = cos_tab; g_q_sin = sin_tab; g_q_rot_dim = rot_dim;
-  const int rc = tribe_internal_attention_fused(qkv, B, T, heads, dim_head, scale, out, s);
-  g_q_cos = g_q_sin = nullptr; g_q_rot_dim = 0;
-  return rc;
-}
-
-int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
-                                   hipStream_t s) {
+static tribe_attention_desc fused_desc(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out) {
   const int64_t inner = (int64_t)heads * dim_head;
   tribe_attention_desc d;
   d.q = qkv; d.k = qkv + inner; d.v = qkv + 2 * inner;
@@ -1033,5 +1019,21 @@ int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, in
   d.out = out; d.ld_out = inner;
   d.B = B; d.T = T; d.heads_q = heads; d.heads_kv = heads; d.dim_head = dim_head; d.causal = 0; d.scale = scale;
   d.rel_qe = nullptr; d.ld_rel_qe = 0; d.rel_stride_h = 0; d.rel_left = d.rel_right = 0;
-  return tribe_attention_fwd_ex(&d, (void*)s);
+  return d;
+}
+
+// as tribe_internal_attention_fused, with the partial rotary of Q (interleaved pairs) applied inside the kernel: q in `qkv` is NOT
+// rotated, k is.  Only valid while tribe_internal_attention_rotates_q(dim_head).
+int tribe_internal_attention_fused_qrot(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
+                                        const float* cos_tab, const float* sin_tab, int rot_dim, hipStream_t s) {
+  TRIBE_REQUIRE(tribe_internal_attention_rotates_q(dim_head) && cos_tab && sin_tab && rot_dim > 0 && rot_dim % 16 == 0 && rot_dim <= dim_head,
+                "tribe_internal_attention_fused_qrot: unsupported configuration");
+  const tribe_attention_desc d = fused_desc(qkv, B, T, heads, dim_head, scale, out);
+  return attention_dispatch(&d, cos_tab, sin_tab, rot_dim, (void*)s);
+}
+
+int tribe_internal_attention_fused(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out,
+                                   hipStream_t s) {
+  const tribe_attention_desc d = fused_desc(qkv, B, T, heads, dim_head, scale, out);
+  return attention_dispatch(&d, nullptr, nullptr, 0, (void*)s);
 }

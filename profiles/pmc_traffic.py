@@ -29,7 +29,7 @@ fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    m = re.search(r"gemm_nt_\d+x\d+x64<(\d), (\d+)>", k)
+    m = re.search(r"gemm_nt_\d+x\d+x64<(\d), (\d+)(?:, \d+)?>", k)
     if m:
         role = int(m.group(2))
         name = ROLES[role] if role < len(ROLES) else "ext_epilogue"
