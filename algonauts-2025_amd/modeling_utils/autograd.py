@@ -161,7 +161,7 @@ class Linear(torch.autograd.Function):
         dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
         wgrad(dpre, x, dw, M, N, K, Np, K)
         dw = dw[:, : w.shape[1]] if w.shape[1] != K else dw
-        db = colsum(dpre, M, N) if ctx.has_b else None
+        db = colsum(dpre, M, Np) if ctx.has_b else None   # over the padded row (stride Np); the zero pad columns are dropped below
         if Np != N and db is not None:
             db = db[:N]
         return dx, dw, db, dres, drs, None, None

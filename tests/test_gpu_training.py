@@ -79,6 +79,24 @@ def test_autograd_blocks_vs_torch():
     torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("M,K,N", [(256, 128, 192), (320, 256, 136), (192, 128, 100)])
+def test_linear_weight_gradient_through_the_transposed_operand_gemm(M, K, N):
+    """M % 64 == 0 with N, K >= 128 sends dW = dY^T X through tribe_gemm_desc.trans_ab (no explicit transposes; N = 136 pads dY's row
+    stride to 192, N = 100 stays on the transpose route): same gradients as torch either way."""
+    from modeling_utils import autograd as ag
+
+    g = torch.Generator().manual_seed(13)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K**0.5); b = torch.randn(N, generator=g)
+    dy = bf(torch.randn(M, N, generator=g))
+    xt, wt, bt = (t.clone().requires_grad_() for t in (x, w, b))
+    (xt @ wt.t() + bt).backward(dy)
+    xg = x.cuda().bfloat16().requires_grad_(); wg, bg = (t.cuda().requires_grad_() for t in (w, b))
+    ag.Linear.apply(xg, wg, bg, None, None, True).backward(dy.cuda())
+    for name, got, want in (("dx", xg.grad.float(), xt.grad), ("dw", wg.grad, wt.grad), ("db", bg.grad, bt.grad)):
+        assert _rel(got.cpu(), want) < 2e-2, name
+
+
 def test_scalenorm_fork_sums_both_branches_in_its_backward():
     """ScaleNormFork + a residual consumer with raw_res_grad=True == the plain pre-norm residual block y = Linear(norm(x)) + x * rs."""
     from modeling_utils import autograd as ag
