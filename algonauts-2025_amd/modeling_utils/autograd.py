@@ -388,21 +388,27 @@ class Attention(torch.autograd.Function):
                   sC=(h * T * Tp, T * Tp), a_off=row0 * inner, b_off=v_off)
             # dS = P * (dP - rowsum(P dP)) * scale
             check(lib().tribe_softmax_bwd(P.data_ptr(), dP.data_ptr(), Z * T, T, Tp, Tp, Tp, scale, dS.data_ptr(), Tp, st), "tribe_softmax_bwd")
-            # transposed operands:  per (b, h) views of q / k / dO [T, d] -> [d, Tp];  P, dS [T, T] -> [T, Tp]
-            qT = _head_transpose(qkv, nb, h, T, d, ld, q_off)
+            # dQ[q, :] = sum_key dS[q, key] K[key, :]: the reduction runs along the rows of K -> per (b, h) transposed view [d, Tp]
             kT = _head_transpose(qkv, nb, h, T, d, ld, k_off)
-            doT = _head_transpose(dout, nb, h, T, d, inner, row0 * inner)
-            PT = transpose_bf16(P, Z, T, T, T * Tp, Tp)
-            dST = transpose_bf16(dS, Z, T, T, T * Tp, Tp)
-            # dV[key, :] = sum_q P[q, key] dO[q, :]
-            _gemm(PT, doT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
-                  sC=(T * ld, d), c_off=v_off)
-            # dQ[q, :] = sum_key dS[q, key] K[key, :]
             _gemm(dS, kT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
                   sC=(T * ld, d), c_off=q_off)
-            # dK[key, :] = sum_q dS[q, key] Q[q, :]
-            _gemm(dST, qT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
-                  sC=(T * ld, d), c_off=k_off)
+            if T % 64 == 0 and d % 8 == 0:
+                # dV[key, :] = sum_q P[q, key] dO[q, :] and dK[key, :] = sum_q dS[q, key] Q[q, :]: both factors have the reduction index q on
+                # their ROWS -- the transposed-operand form of the GEMM (desc.trans_ab) reads P / dS [T, Tp] and the dO / q head slices as
+                # they lie: no P^T, dS^T ([B h, T, T] each), q^T, dO^T
+                _gemm(P, dout, dqkv, lda=Tp, ldb=inner, ldc=ld, M=T, N=d, K=T, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(T * inner, d),
+                      sC=(T * ld, d), b_off=row0 * inner, c_off=v_off, trans_ab=True)
+                _gemm(dS, qkv, dqkv, lda=Tp, ldb=ld, ldc=ld, M=T, N=d, K=T, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(T * ld, d),
+                      sC=(T * ld, d), b_off=q_off, c_off=k_off, trans_ab=True)
+            else:
+                qT = _head_transpose(qkv, nb, h, T, d, ld, q_off)
+                doT = _head_transpose(dout, nb, h, T, d, inner, row0 * inner)
+                PT = transpose_bf16(P, Z, T, T, T * Tp, Tp)
+                dST = transpose_bf16(dS, Z, T, T, T * Tp, Tp)
+                _gemm(PT, doT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
+                      sC=(T * ld, d), c_off=v_off)
+                _gemm(dST, qT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
+                      sC=(T * ld, d), c_off=k_off)
         return dqkv, None, None, None, None, None
 
 

@@ -79,6 +79,26 @@ def test_autograd_blocks_vs_torch():
     torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,T,h,d", [(2, 128, 2, 64), (1, 192, 3, 384), (2, 70, 2, 64)])
+def test_attention_backward_with_and_without_explicit_transposes(B, T, h, d):
+    """T % 64 == 0 sends dV = P^T dO and dK = dS^T Q through the transposed-operand GEMM (batched over (sequence, head), strided head
+    slices as operands); T = 70 keeps the explicit transposes.  Gradients of the fused qkv buffer vs torch."""
+    from modeling_utils import autograd as ag
+
+    g = torch.Generator().manual_seed(14)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g)); dout = bf(torch.randn(B * T, h * d, generator=g))
+    qt = qkv.clone().requires_grad_()
+    q, k, v = (t.transpose(1, 2) for t in qt.view(B, T, 3, h, d).unbind(2))
+    att = (torch.einsum("bhid,bhjd->bhij", q, k) * d**-0.5).softmax(-1)
+    torch.einsum("bhij,bhjd->bhid", att, v).transpose(1, 2).reshape(B * T, h * d).backward(dout)
+    qg = qkv.cuda().bfloat16().requires_grad_()
+    ag.Attention.apply(qg, B, T, h, d, d**-0.5).backward(dout.cuda().bfloat16())
+    got, want = qg.grad.float().cpu().view(B, T, 3, h, d), qt.grad.view(B, T, 3, h, d)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert _rel(got[:, :, i], want[:, :, i]) < 3e-2, name
+
+
 @pytest.mark.parametrize("M,K,N", [(256, 128, 192), (320, 256, 136), (192, 128, 100)])
 def test_linear_weight_gradient_through_the_transposed_operand_gemm(M, K, N):
     """M % 64 == 0 with N, K >= 128 sends dW = dY^T X through tribe_gemm_desc.trans_ab (no explicit transposes; N = 136 pads dY's row
