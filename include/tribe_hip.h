@@ -165,9 +165,11 @@ int tribe_rotary_fwd(uint16_t* x, int64_t rows, int64_t T, int64_t row_stride, i
 size_t tribe_attention_workspace_bytes(int64_t B, int64_t T, int32_t heads, int32_t dim_head);
 /* 0 (default): fused flash-style kernel for dim_head in {64,128,192,384}, else the materialised path;
  * 1: always materialise scores (QK^T GEMM -> f32 softmax -> PV GEMM), kept as a cross-check;
- * 2: fused, but dim_head 384 on the 16-query-row kernel of the other head sizes instead of its own 32-row, one-wave-per-SIMD
- *    kernel (A/B measurements);
- * 3: fused, dim_head 384 on the key-split kernel (two waves per SIMD, each owning half of the head dimension).
+ * 2: fused, but dim_head 384 and 64 on the 16-query-row kernel of the other head sizes instead of their own kernels
+ *    (A/B measurements);
+ * 3: fused, dim_head 384 on the key-split kernel (two waves per SIMD, each owning half of the head dimension);
+ * 4: fused, dim_head 64 (bidirectional) on the 64-rows-per-wave kernel in phase-separated order (the default interleaves the two row
+ *    tiles of a wave); 5: dim_head 64 on the anti-phase 8-wave kernel.  Modes 2-5 exist for A/B measurements (csrc/attention_d64.hip).
  * Process-wide switch: set it from one thread, between launches. */
 int tribe_attention_set_mode(int32_t mode);
 int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, int32_t heads, int32_t dim_head, float scale,
