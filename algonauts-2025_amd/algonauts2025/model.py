@@ -234,6 +234,7 @@ class FmriEncoder(nn.Module):
         x = x.reshape(B * T, -1).contiguous()
         enc = self.encoder
         cos, sin = enc.packed().tables(T, x.device)
+        neg_sin = (-sin).contiguous() if sin is not None else None      # the backward's rotation by -theta, negated once per step
         gs, eps = enc.final_norm.gain_scale, enc.final_norm.eps
         scale = enc.dim_head**-0.5
         for i in range(enc.depth):
@@ -243,8 +244,10 @@ class FmriEncoder(nn.Module):
             xn, xr = ag.ScaleNormFork.apply(x, norms_a[0].g, gs, eps, res_a.residual_scale)
             qkv = ag.QKVLinear.apply(xn, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
             if enc.rotary_emb_dim:
-                qkv = ag.Rotary.apply(qkv, cos, sin, T, enc.heads, enc.dim_head, enc.rotary_emb_dim, enc.rotary_interleaved)
-            ao = ag.Attention.apply(qkv, B, T, enc.heads, enc.dim_head, scale)
+                ao, _ = ag.RotaryAttention.apply(qkv, cos, sin, neg_sin, B, T, enc.heads, enc.dim_head, scale, enc.rotary_emb_dim,
+                                                 enc.rotary_interleaved)
+            else:
+                ao = ag.Attention.apply(qkv, B, T, enc.heads, enc.dim_head, scale)
             x = ag.Linear.apply(ao, attn.to_out.weight, None, xr, res_a.residual_scale, True, True)
             xn, xr = ag.ScaleNormFork.apply(x, norms_f[0].g, gs, eps, res_f.residual_scale)
             x = ag.FeedForward.apply(xn, ff.ff[0][0].weight, ff.ff[0][0].bias, ff.ff[2].weight, ff.ff[2].bias, xr, res_f.residual_scale, True)

@@ -155,7 +155,7 @@ class Linear(torch.autograd.Function):
         dpre = cast_bf16(dy)
         if Np != N:
             dpre = torch.nn.functional.pad(dpre, (0, Np - N))  # zero K-padding for the dgrad GEMM (N % 64 != 0 only)
-        dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+        dx = torch.empty(M, K, dtype=x.dtype, device=x.device)   # x is bf16: autograd would cast an f32 gradient in a pass of its own
         _gemm(dpre, wt, dx, lda=Np, ldb=Np, ldc=K, M=M, N=K, K=Np)
         # dW[n, k] = sum_m dpre[m, n] x[m, k]
         dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
@@ -221,7 +221,7 @@ class QKVLinear(torch.autograd.Function):
         N3, Np = 3 * N, wt.shape[1]
         if Np != N3:
             dpre = torch.nn.functional.pad(dpre, (0, Np - N3))
-        dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+        dx = torch.empty(M, K, dtype=x.dtype, device=x.device)   # x is bf16: autograd would cast an f32 gradient in a pass of its own
         _gemm(dpre, wt, dx, lda=Np, ldb=Np, ldc=K, M=M, N=K, K=Np)
         dw = torch.empty(N3, K, dtype=torch.float32, device=x.device)
         wgrad(dpre, x, dw, M, N3, K, Np, K)
@@ -268,7 +268,7 @@ class FeedForward(torch.autograd.Function):
         wgrad(dob, h, dw2, M, D, Fh, D, Fh)
         db1 = colsum(dpre, M, Fh)
         _, w1t = PACKS.get(w1)                                  # [D, Fh]
-        dx = torch.empty(M, D, dtype=torch.float32, device=x.device)
+        dx = torch.empty(M, D, dtype=x.dtype, device=x.device)   # as in Linear.backward
         _gemm(dpre, w1t, dx, lda=Fh, ldb=Fh, ldc=D, M=M, N=D, K=Fh)
         dw1 = torch.empty(Fh, D, dtype=torch.float32, device=x.device)
         wgrad(dpre, x, dw1, M, Fh, D, Fh, D)
@@ -357,6 +357,7 @@ class Attention(torch.autograd.Function):
         out = ops.attention(qkv, B, T, heads, dim_head, scale)
         ctx.save_for_backward(qkv)
         ctx.meta = (B, T, heads, dim_head, scale)
+        ctx.rotary = None
         return out
 
     @staticmethod
@@ -409,7 +410,30 @@ class Attention(torch.autograd.Function):
                       sC=(T * ld, d), c_off=v_off)
                 _gemm(dST, qT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
                       sC=(T * ld, d), c_off=k_off)
+        if ctx.rotary is not None:   # RotaryAttention: rotate dq, dk back in place -- dqkv is this function's own buffer
+            cos, neg_sin, rot_dim, interleaved = ctx.rotary
+            ops.rotary_(dqkv, T, h, d, rot_dim, cos, neg_sin, interleaved)
         return dqkv, None, None, None, None, None
+
+
+class RotaryAttention(torch.autograd.Function):
+    """Rotary (in place on the q and k heads of the fused qkv buffer) + attention as ONE node: the backward rotates dq, dk by -theta in the
+    gradient buffer it allocated itself.  As two nodes (Rotary, Attention) the rotation had to work on a clone of the incoming gradient
+    (302 MB copied per layer and step at B = 16) and negate the sine table every call."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, neg_sin, B: int, T: int, heads: int, dim_head: int, scale: float, rot_dim: int, interleaved: bool):
+        ctx.mark_dirty(qkv)
+        ops.rotary_(qkv, T, heads, dim_head, rot_dim, cos, sin, interleaved)
+        out = ops.attention(qkv, B, T, heads, dim_head, scale)
+        ctx.save_for_backward(qkv)
+        ctx.meta = (B, T, heads, dim_head, scale)
+        ctx.rotary = (cos, neg_sin, rot_dim, interleaved)
+        return out, qkv
+
+    @staticmethod
+    def backward(ctx, dout, _dqkv_alias):
+        return (Attention.backward(ctx, dout)[0],) + (None,) * 10
 
 
 def _head_transpose(x: torch.Tensor, nb: int, h: int, T: int, d: int, ld: int, off: int) -> torch.Tensor:
