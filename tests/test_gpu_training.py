@@ -117,6 +117,24 @@ def test_linear_weight_gradient_through_the_transposed_operand_gemm(M, K, N):
         assert _rel(got.cpu(), want) < 2e-2, name
 
 
+def test_gelu_backward_epilogue():
+    """act = GELU_BWD: out = (A B^T) * gelu'(pre) with the derivative from the forward's Phi polynomial + one exp2 (gemm_common.h gelu_grad2).
+    A = identity rows pick single B entries, so the f32 output isolates the factor: |gelu' error| <= 1e-4 over pre in [-6, 6]."""
+    from modeling_utils import autograd as ag
+    from tribe_hip import _lib
+
+    M = N = K = 256
+    a = torch.eye(M, K).cuda().bfloat16()
+    b = torch.ones(N, K).cuda().bfloat16()            # (A B^T)[m, n] = 1
+    pre = torch.linspace(-6, 6, M * N).view(M, N)
+    pre_bf = pre.to(torch.bfloat16)
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ag._gemm(a, b, out, lda=K, ldb=K, ldc=N, M=M, N=N, K=K, act=_lib.ACT_GELU_BWD, aux=pre_bf.cuda())
+    x = pre_bf.double()
+    want = 0.5 * (1 + torch.erf(x / 2**0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    assert float((out.cpu().double() - want).abs().max()) < 1e-4
+
+
 def test_scalenorm_fork_sums_both_branches_in_its_backward():
     """ScaleNormFork + a residual consumer with raw_res_grad=True == the plain pre-norm residual block y = Linear(norm(x)) + x * rs."""
     from modeling_utils import autograd as ag
