@@ -29,6 +29,29 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int64_t rows, 
   }
 }
 
+// the unpadded, contiguous case (every weight of the encoder: cols % 64 == 0) is a flat f32 -> bf16 cast: 32 elements per thread and
+// trip, eight 16-byte nontemporal loads in flight, no index arithmetic (the general kernel above ran at 2.6 TB/s over the 5.7 GB of
+// weights a training step re-packs)
+__global__ __launch_bounds__(256) void cast_flat_kernel(const float* __restrict__ src, int64_t n32, unsigned short* __restrict__ dst) {
+  // a workgroup converts 8192 consecutive elements per trip: load k of lane l is float4 number 256 k + l of the span, so every
+  // wave-instruction reads (and every store writes) one contiguous run
+  const int64_t spans = (n32 * 32 + 8191) / 8192, n4 = n32 * 8;
+  for (int64_t sp = blockIdx.x; sp < spans; sp += gridDim.x) {
+    const int64_t base4 = sp * 2048 + threadIdx.x;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (base4 + 256 * k < n4) v[k] = load_nt_f4(src + (base4 + 256 * k) * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (base4 + 256 * k >= n4) continue;
+      u16x4_t o;
+      o[0] = f32_to_bf16(v[k].x); o[1] = f32_to_bf16(v[k].y); o[2] = f32_to_bf16(v[k].z); o[3] = f32_to_bf16(v[k].w);
+      *(u16x4_t*)(dst + (base4 + 256 * k) * 4) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // generic tiled transpose+cast:  out[z][j][i] (bf16, ld_out, zero padded to i_pad x j_pad)
 //   = reduce_l in[z][l][i][j]   with in element strides (s_z, s_l, s_i, 1), j contiguous.
@@ -591,6 +614,12 @@ extern "C" int tribe_pack_weight_bf16(const float* src, int64_t rows, int64_t co
                 "tribe_pack_weight_bf16: bad shape rows=%lld cols=%lld rows_pad=%lld cols_pad=%lld ld=%lld", (long long)rows,
                 (long long)cols, (long long)rows_pad, (long long)cols_pad, (long long)ld_src);
   TRIBE_REQUIRE(cols_pad % 8 == 0 && ((uintptr_t)dst % 16) == 0, "tribe_pack_weight_bf16: cols_pad %% 8 and 16-byte dst required");
+  if (rows == rows_pad && cols == cols_pad && ld_src == cols && (rows * cols) % 32 == 0 && ((uintptr_t)src % 16) == 0) {
+    const int64_t n32 = rows * cols / 32;
+    hipLaunchKernelGGL(cast_flat_kernel, dim3(grid_for((n32 * 32 + 8191) / 8192 * 256, 256)), dim3(256), 0, (hipStream_t)stream, src, n32, dst);
+    TRIBE_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(rows_pad * (cols_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream, src,
                      rows, cols, ld_src, dst, rows_pad, cols_pad);
   TRIBE_LAUNCH_CHECK();

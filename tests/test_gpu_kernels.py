@@ -178,6 +178,9 @@ def test_pack_weights(ops):
     assert p.shape == (50, 128)
     torch.testing.assert_close(p[:, :100], bf(w), rtol=0, atol=0)
     assert p[:, 100:].abs().max() == 0
+    for rows, cols in ((384, 3072), (33, 64), (7, 128)):   # unpadded + contiguous: the flat cast (32 per thread) and its fallbacks
+        wu = torch.randn(rows, cols, generator=g)
+        torch.testing.assert_close(ops.pack_weight(_dev(wu)).float().cpu(), bf(wu), rtol=0, atol=0)
     sw = torch.randn(3, 70, 45, generator=g)
     ps = ops.pack_subject_weights(_dev(sw)).float().cpu()
     assert ps.shape == (3, 128, 128)
