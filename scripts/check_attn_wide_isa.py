@@ -3,7 +3,7 @@
   * no compiler-generated v_accvgpr_* or MFMA outside the ASMSTART / ASMEND blocks (a0..a191 hold O^T and belong to the asm
     statements of attn_acc_regs.h; the compiler must not allocate accumulator registers of its own),
   * prints the register budget and the instruction mix of the key loop.
-Usage: python scripts/check_attn_wide_isa.py"""
+Usage: python scripts/check_attn_wide_isa.py [--no-gemm]"""
 import re
 import subprocess
 import sys
@@ -12,10 +12,29 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "algonauts-2025_amd" / "csrc"
-with tempfile.TemporaryDirectory() as tmp:
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-I{CSRC}", "-save-temps", "-c",
-                    str(CSRC / "attention.hip"), "-o", f"{tmp}/attn.o"], check=True, cwd=tmp, capture_output=True)
-    text = Path(tmp, "attention-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+
+
+def device_isa(sources: list[str]) -> dict[str, str]:
+    """gfx950 assembly of each source, the compilations running side by side (device side only)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for src in sources:
+            out = Path(tmp, src.replace(".hip", ".s"))
+            procs.append((src, out, subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                                                      f"-I{CSRC}", f"-I{ROOT / 'include'}", str(CSRC / src), "-o", str(out)],
+                                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=tmp)))
+        isa = {}
+        for src, out, proc in procs:
+            _, err = proc.communicate()
+            if proc.returncode:
+                raise SystemExit(f"hipcc failed on {src}:\n{err.decode()[-2000:]}")
+            isa[src] = out.read_text()
+        return isa
+
+
+WITH_GEMM = "--no-gemm" not in sys.argv[1:]   # gemm.hip takes two minutes to compile (its role instantiations); the unit test skips it
+ISA = device_isa(["attention.hip", "attention_d64.hip"] + (["gemm.hip"] if WITH_GEMM else []))
+text = ISA["attention.hip"]
 def audit(kernel: str, max_regs: int) -> bool:
     m = re.search(rf"^(_ZN\S*{kernel}\S*):.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
     if m is None:
@@ -46,10 +65,7 @@ ok = audit("attn_fwd_wide384", 512) & audit("attn_fwd_ksplit384", 256)
 # The DH = 64 kernels (attention_d64.hip) and the two forms of the 256^2 GEMM use compiler-allocated registers throughout; what must hold
 # is the budget of two waves per SIMD WITHOUT scratch: a spilled accumulator or Q fragment is reloaded every key tile / K-tile.
 def no_scratch(source: str, kernels: list[str]) -> bool:
-    with tempfile.TemporaryDirectory() as tmp2:
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT / 'include'}", "-save-temps",
-                        "-c", str(CSRC / source), "-o", f"{tmp2}/x.o"], check=True, cwd=tmp2, capture_output=True)
-        isa = Path(tmp2, source.replace(".hip", "-hip-amdgcn-amd-amdhsa-gfx950.s")).read_text()
+    isa = ISA[source]
     good = True
     for kernel in kernels:
         found = re.findall(rf"\.amdhsa_kernel (_ZN\S*{kernel}\S*)\n(.*?)\.end_amdhsa_kernel", isa, re.S)
@@ -68,7 +84,8 @@ def no_scratch(source: str, kernels: list[str]) -> bool:
 
 
 ok &= no_scratch("attention_d64.hip", ["attn_fwd_d64_kernel", "attn_fwd_d64_pair_kernel"])
-ok &= no_scratch("gemm.hip", ["gemm_nt_256x256x64"])
+if WITH_GEMM:
+    ok &= no_scratch("gemm.hip", ["gemm_nt_256x256x64"])
 if not ok:
     sys.exit(1)
 print("OK: no scratch, no compiler accumulator-register traffic")

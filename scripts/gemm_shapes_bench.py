@@ -12,7 +12,9 @@ from tribe_hip import ops  # noqa: E402
 shapes = [("vjepa2 qkv", 8192, 4224, 1408), ("vjepa2 proj", 8192, 1408, 1408), ("vjepa2 fc1", 8192, 6144, 1408), ("vjepa2 fc2", 8192, 1408, 6144),
           ("vjepa2 qkv x2", 16384, 4224, 1408), ("vjepa2 proj x2", 16384, 1408, 1408), ("vjepa2 fc2 x2", 16384, 1408, 6144),
           ("w2v qkv x8", 24000, 3072, 1024), ("w2v ffn1 x8", 24000, 4096, 1024), ("w2v ffn2 x8", 24000, 1024, 4096), ("w2v out x8", 24000, 1024, 1024),
-          ("w2v qkv x1", 3000, 3072, 1024), ("w2v ffn1 x1", 3000, 4096, 1024), ("w2v ffn2 x1", 3000, 1024, 4096)]
+          ("w2v qkv x1", 3000, 3072, 1024), ("w2v ffn1 x1", 3000, 4096, 1024), ("w2v ffn2 x1", 3000, 1024, 4096),
+          ("tribe B=4 qkv", 4096, 9216, 3072), ("tribe B=4 out", 4096, 3072, 3072), ("tribe B=4 ff2", 4096, 3072, 12288),
+          ("tribe B=4 projector", 4096, 1024, 4096)]
 for name, M, N, K in shapes:
     a = torch.randn(M, K, device="cuda").bfloat16()
     b = torch.randn(N, K, device="cuda").bfloat16()

@@ -169,7 +169,7 @@ def test_attention_kernels_own_their_accumulator_registers():
     if not Path("/opt/rocm/bin/hipcc").exists() and shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
     root = Path(__file__).resolve().parent.parent
-    p = subprocess.run([sys.executable, str(root / "scripts" / "check_attn_wide_isa.py")], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, str(root / "scripts" / "check_attn_wide_isa.py"), "--no-gemm"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     # the generated header is in step with its generator
     before = (root / "algonauts-2025_amd" / "csrc" / "attn_acc_regs.h").read_text()
