@@ -350,7 +350,10 @@ class Attention(torch.autograd.Function):
     """softmax(q k^T * scale) v per (batch, head) on a fused bf16 qkv [B*T, 3*inner]; forward = fused flash kernel,
     backward = materialised (S, P recomputed per batch chunk; five MFMA GEMM products per head)."""
 
-    CHUNK_BYTES = 256 << 20
+    # f32 score bytes per chunk of sequences.  Same box, B = 16 (scripts/train_bench.py attn-chunk=N): 7 sequences (256 MiB) 112.0 ms,
+    # 4 sequences 110.9, 2 sequences 117.4, 1 sequence 122.5 -- smaller chunks keep more of S / P / dP / dS in the Infinity Cache but
+    # leave the batched GEMMs under one round of tiles
+    CHUNK_BYTES = 144 << 20
 
     @staticmethod
     def forward(ctx, qkv, B: int, T: int, heads: int, dim_head: int, scale: float):

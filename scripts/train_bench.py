@@ -24,6 +24,10 @@ from modeling_utils.optim import HipAdam  # noqa: E402
 
 stock = "torch-adam" in sys.argv[2:]
 use_graph = "graph" in sys.argv[2:]
+for _a in sys.argv[2:]:
+    if _a.startswith("attn-chunk="):   # sequences per chunk of the materialised attention backward (experiment: keep S / P / dP / dS cache-resident)
+        from modeling_utils import autograd as _ag
+        _ag.Attention.CHUNK_BYTES = int(_a.split("=")[1]) * 8 * 1024 * 1024 * 4
 opt = torch.optim.Adam(model.parameters(), lr=1e-4) if stock else HipAdam(model.parameters(), lr=1e-4)   # defaults.py:126-133
 g = torch.Generator().manual_seed(1)
 data = {m: torch.stack([torch.randn(L, D, T, generator=g).bfloat16() for _ in range(B)]).to(dev) for m in fdims}
