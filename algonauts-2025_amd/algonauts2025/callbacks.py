@@ -161,7 +161,7 @@ class StochasticWeightAveraging:
         table = np.zeros(len(self._params), dtype=_lib.ADAM_TENSOR_DTYPE)
         owner, start = [], []
         for i, (p, a) in enumerate(zip(self._params, self.averages)):
-            table[i] = (a.data_ptr(), p.data_ptr(), 0, 0, p.numel())
+            table[i] = (a.data_ptr(), p.data_ptr(), 0, 0, p.numel(), 0)
             s = np.arange(0, p.numel(), chunk, dtype=np.int64)
             owner.append(np.full(len(s), i, dtype=np.int32))
             start.append(s)

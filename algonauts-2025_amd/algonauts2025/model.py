@@ -233,8 +233,7 @@ class FmriEncoder(nn.Module):
             x = x + self.subject_embed(subject_id)              # model.py:171-172
         x = x.reshape(B * T, -1).contiguous()
         enc = self.encoder
-        cos, sin = enc.packed().tables(T, x.device)
-        neg_sin = (-sin).contiguous() if sin is not None else None      # the backward's rotation by -theta, negated once per step
+        cos, sin, neg_sin = enc.rotary_tables(T, x.device)     # neg_sin: the backward's rotation by -theta
         gs, eps = enc.final_norm.gain_scale, enc.final_norm.eps
         scale = enc.dim_head**-0.5
         for i in range(enc.depth):

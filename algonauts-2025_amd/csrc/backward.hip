@@ -441,16 +441,30 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const tribe_adam_tensor*
   };
   if (vec) {
     const int64_t n4 = (i1 - i0) / 4;
+    const bool shadow4 = t.p_bf16 && (((uintptr_t)t.p_bf16) & 7) == 0;
     for (int64_t q = threadIdx.x; q < n4; q += 256) {
       const int64_t i = i0 + 4 * q;
       float4 p = *(float4*)(t.p + i), m = *(float4*)(t.m + i), v = *(float4*)(t.v + i);
       const float4 g = *(const float4*)(t.g + i);
       update(p.x, g.x, m.x, v.x); update(p.y, g.y, m.y, v.y); update(p.z, g.z, m.z, v.z); update(p.w, g.w, m.w, v.w);
       *(float4*)(t.p + i) = p; *(float4*)(t.m + i) = m; *(float4*)(t.v + i) = v;
+      if (shadow4) {   // the bf16 operand copy the next forward's GEMMs read: written here instead of by a cast pass over the f32 weights
+        u16x4_t o;
+        o[0] = f32_to_bf16(p.x); o[1] = f32_to_bf16(p.y); o[2] = f32_to_bf16(p.z); o[3] = f32_to_bf16(p.w);
+        *(u16x4_t*)(t.p_bf16 + i) = o;
+      } else if (t.p_bf16) {
+        t.p_bf16[i] = f32_to_bf16(p.x); t.p_bf16[i + 1] = f32_to_bf16(p.y); t.p_bf16[i + 2] = f32_to_bf16(p.z); t.p_bf16[i + 3] = f32_to_bf16(p.w);
+      }
     }
-    for (int64_t i = i0 + 4 * n4 + threadIdx.x; i < i1; i += 256) update(t.p[i], t.g[i], t.m[i], t.v[i]);
+    for (int64_t i = i0 + 4 * n4 + threadIdx.x; i < i1; i += 256) {
+      update(t.p[i], t.g[i], t.m[i], t.v[i]);
+      if (t.p_bf16) t.p_bf16[i] = f32_to_bf16(t.p[i]);
+    }
   } else {
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) update(t.p[i], t.g[i], t.m[i], t.v[i]);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+      update(t.p[i], t.g[i], t.m[i], t.v[i]);
+      if (t.p_bf16) t.p_bf16[i] = f32_to_bf16(t.p[i]);
+    }
   }
 }
 

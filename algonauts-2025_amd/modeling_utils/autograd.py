@@ -94,13 +94,25 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
 
 class _WeightPacks:
     """bf16 W [N, K_pad] and W^T [K, N_pad] per (tensor object, version) of an f32 weight; entries die with the tensor
-    (temporaries such as the fused q|k|v weight are rebuilt every step, parameters only when they were updated)."""
+    (temporaries are rebuilt every step, parameters only when they were updated).  An unpadded pack (K % 64 == 0: a plain element-wise
+    cast) is registered as the parameter's bf16 shadow (modeling_utils/shadow.py): HipAdam's kernel then writes it while it updates the
+    parameter and `_refreshed` records the new version -- no cast pass after the step; W^T is re-derived from the bf16 pack."""
 
     def __init__(self) -> None:
-        self._c: dict[int, tuple[tp.Any, tuple, torch.Tensor, torch.Tensor]] = {}
+        self._c: dict[int, list] = {}     # id(w) -> [weakref, sig, pack, packT]
+
+    def _refreshed(self, key: int, w_ref: tp.Any, version: int) -> None:
+        hit, w = self._c.get(key), w_ref()
+        if hit is None or w is None or hit[0]() is not w:
+            return
+        hit[1] = (w.data_ptr(), version, tuple(w.shape))
+        N, K = w.shape
+        hit[3] = transpose_bf16(hit[2], 1, N, K, 0, hit[2].shape[1])[0]     # [K, N_pad64] from the fresh bf16 pack
 
     def get(self, w: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         import weakref
+
+        from . import shadow
 
         key = id(w)
         sig = (w.data_ptr(), w._version, tuple(w.shape))
@@ -108,8 +120,11 @@ class _WeightPacks:
         if hit is None or hit[0]() is not w or hit[1] != sig:
             wd = w.detach().contiguous()
             N, K = wd.shape
-            hit = (weakref.ref(w, lambda _r, k=key: self._c.pop(k, None)), sig, ops.pack_weight(wd), transpose_bf16(wd, 1, N, K, 0, K)[0])
+            ref = weakref.ref(w, lambda _r, k=key: self._c.pop(k, None))
+            hit = [ref, sig, ops.pack_weight(wd), transpose_bf16(wd, 1, N, K, 0, K)[0]]
             self._c[key] = hit
+            if hit[2].shape == wd.shape and w.is_contiguous() and isinstance(w, torch.nn.Parameter):
+                shadow.register(w, hit[2], lambda version, k=key, r=ref: self._refreshed(k, r, version))
         return hit[2], hit[3]
 
 
@@ -169,14 +184,27 @@ class Linear(torch.autograd.Function):
 
 class _FusedQKVPacks:
     """bf16 [3N, K] (q | k | v rows) and its transpose [K, 3N] for one attention block, rebuilt only when one of the three f32
-    weights was written (optimizer step): each weight is packed STRAIGHT into its row slice -- no f32 `torch.cat` of the three
-    matrices per layer and step (113 MB written + read back, plus the split in backward), which model.py:228 of round 1 did."""
+    weights was written: each weight is packed STRAIGHT into its row slice -- no f32 `torch.cat` of the three matrices per layer and
+    step (113 MB written + read back, plus the split in backward), which model.py:228 of round 1 did.  The three row slices are the
+    parameters' bf16 shadows (see _WeightPacks): after a HipAdam step only the transpose is re-derived."""
 
     def __init__(self) -> None:
-        self._c: dict[int, tuple[tp.Any, tuple, torch.Tensor, torch.Tensor]] = {}
+        self._c: dict[int, list] = {}     # id(wq) -> [weakref, sig, fused, fusedT, [weak refs of the three weights]]
+
+    def _refreshed(self, key: int) -> None:
+        hit = self._c.get(key)
+        if hit is None:
+            return
+        ws = [r() for r in hit[4]]
+        if any(w is None for w in ws) or hit[0]() is not ws[0]:
+            return
+        hit[1] = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in ws)   # current once all three were stepped; a partial update repacks
+        hit[3] = None                                                            # the transpose is re-derived on the next get()
 
     def get(self, ws: tuple[torch.Tensor, torch.Tensor, torch.Tensor]) -> tuple[torch.Tensor, torch.Tensor]:
         import weakref
+
+        from . import shadow
 
         key = id(ws[0])
         sig = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in ws)
@@ -185,12 +213,19 @@ class _FusedQKVPacks:
             N, K = ws[0].shape
             if any(tuple(w.shape) != (N, K) for w in ws) or K % 64:
                 raise ValueError("fused q|k|v projection: the three weights must share one [N, K] shape with K % 64 == 0")
-            fused = torch.empty(3 * N, K, dtype=torch.bfloat16, device=ws[0].device)
+            fused = hit[2] if (hit is not None and hit[0]() is ws[0] and hit[2].shape == (3 * N, K)) else \
+                torch.empty(3 * N, K, dtype=torch.bfloat16, device=ws[0].device)
             for i, w in enumerate(ws):
                 wd = w.detach().contiguous()
                 check(lib().tribe_pack_weight_bf16(wd.data_ptr(), N, K, K, fused[i * N:(i + 1) * N].data_ptr(), N, K, _s()), "tribe_pack_weight_bf16")
-            hit = (weakref.ref(ws[0], lambda _r, k=key: self._c.pop(k, None)), sig, fused, transpose_bf16(fused, 1, 3 * N, K, 0, K)[0])
+            hit = [weakref.ref(ws[0], lambda _r, k=key: self._c.pop(k, None)), sig, fused, None, [weakref.ref(w) for w in ws]]
             self._c[key] = hit
+            for i, w in enumerate(ws):
+                if isinstance(w, torch.nn.Parameter) and w.is_contiguous():
+                    shadow.register(w, fused[i * N:(i + 1) * N], lambda version, k=key: self._refreshed(k))
+        if hit[3] is None:
+            N3, K = hit[2].shape
+            hit[3] = transpose_bf16(hit[2], 1, N3, K, 0, K)[0]
         return hit[2], hit[3]
 
 

@@ -96,6 +96,21 @@ class HipEncoder(nn.Module):
     def _sources(self) -> list[torch.Tensor | None]:
         return [p for p in self.parameters()]
 
+    def rotary_tables(self, T: int, device: torch.device) -> tuple[torch.Tensor | None, torch.Tensor | None, torch.Tensor | None]:
+        """(cos, sin, -sin) f32 [T, rot_dim / 2] for the training path: the same tables EncoderPack.tables builds, WITHOUT packing the weights
+        (asking `packed()` for them re-packed every encoder weight after every optimiser step -- 32 casts and 8 f32 q|k|v concatenations
+        per step that only the inference entry point needs)."""
+        if not self.rotary_emb_dim:
+            return None, None, None
+        key = (T, device.index or 0)
+        cache = self.__dict__.setdefault("_rotary_tabs", {})
+        if key not in cache:
+            t = torch.arange(T, device=device, dtype=torch.float32)
+            freqs = torch.einsum("i,j->ij", t, self.rotary_pos_emb.inv_freq.to(device=device, dtype=torch.float32))
+            cos, sin = freqs.cos().contiguous(), freqs.sin().contiguous()
+            cache[key] = (cos, sin, (-sin).contiguous())
+        return cache[key]
+
     def packed(self) -> ops.EncoderPack:
         def build() -> ops.EncoderPack:
             pack = ops.EncoderPack(self.dim, self.depth, self.heads, self.dim_head, int(self.dim * self.ff_mult),

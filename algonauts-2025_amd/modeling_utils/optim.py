@@ -17,6 +17,8 @@ import torch
 from tribe_hip import _lib
 from tribe_hip._lib import check, lib
 
+from . import shadow
+
 
 class HipAdam(torch.optim.Optimizer):
     def __init__(self, params: tp.Any, lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
@@ -73,11 +75,16 @@ class HipAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             for step, params in by_step.items():
                 table = np.zeros(len(params), dtype=_lib.ADAM_TENSOR_DTYPE)
+                shadows: list[tuple[torch.Tensor, tp.Callable[[int], None]]] = []
                 for i, p in enumerate(params):
                     st = self.state[p]
                     g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
                     keep_alive.append(g)                      # a converted gradient must outlive the launch
-                    table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                    sh = shadow.lookup(p)        # bf16 GEMM-operand copy kept by the autograd path: the kernel refreshes it in the same pass
+                    if sh is not None:
+                        shadows.append((p, sh[1]))
+                    table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                sh[0].data_ptr() if sh is not None else 0)
                 owner, start = self._work_list(gi, params)
                 table_t = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(params[0].device)
                 keep_alive.append(table_t)
@@ -87,5 +94,7 @@ class HipAdam(torch.optim.Optimizer):
                 # the kernel wrote through raw pointers: tell autograd (and this build's packed-weight caches, which key on
                 # `_version`) that the parameters changed
                 torch.autograd.graph.increment_version(params)
+                for p, on_update in shadows:
+                    on_update(p._version)
             del keep_alive      # torch's caching allocator keeps freed blocks ordered on the launch stream
         return loss

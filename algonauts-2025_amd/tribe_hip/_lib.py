@@ -25,7 +25,7 @@ i64, i32, f32, vp, sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 
 
 # tribe_feature_piece as a numpy record (tables of pieces are built vectorised on the host and uploaded as bytes)
-ADAM_TENSOR_DTYPE = _np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8")], align=True)   # tribe_adam_tensor
+ADAM_TENSOR_DTYPE = _np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("p_bf16", "<u8")], align=True)   # tribe_adam_tensor
 FEATURE_PIECE_DTYPE = _np.dtype([("src", "<u8"), ("ld", "<i8"), ("src_first", "<i4"), ("src_count", "<i4"), ("dst_first", "<i4"),
                                  ("dst_count", "<i4")], align=True)
 

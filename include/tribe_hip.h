@@ -541,6 +541,8 @@ int tribe_absmax_fwd(const void* x, int32_t x_dtype, int64_t M, int64_t K, int64
  * table[chunk_tensor[c]].  All three arrays live in device memory. */
 typedef struct tribe_adam_tensor {
   float* p; const float* g; float* m; float* v; int64_t n;
+  uint16_t* p_bf16;   /* optional (NULL = none): bf16 copy of the updated parameter, same element order -- the packed GEMM operand of the next
+                       * forward, written by the optimiser step instead of a separate cast pass (tribe_adam_step only) */
 } tribe_adam_tensor;
 int64_t tribe_adam_chunk_elems(void);
 int tribe_adam_step(const tribe_adam_tensor* table, const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, float lr,

@@ -349,6 +349,34 @@ def test_hip_adam_matches_torch_adam():
         HipAdam([cpu_param], lr=1e-3).step()                      # no CPU fallback
 
 
+def test_hip_adam_refreshes_the_bf16_operand_copies_of_the_weights():
+    """A weight that went through ag.Linear / ag.QKVLinear has a bf16 shadow (its packed GEMM operand); HipAdam's kernel writes it in the
+    same pass as the f32 update, so after the step the cached pack IS bf16(w) -- same buffer, no cast pass -- and its transpose follows."""
+    from modeling_utils import autograd as ag
+    from modeling_utils.optim import HipAdam
+
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(128, 192, bias=False).cuda()
+    wq, wk, wv = (torch.nn.Parameter(torch.randn(64, 128, device="cuda") * 0.1) for _ in range(3))
+    opt = HipAdam([lin.weight, wq, wk, wv], lr=1e-2)
+    x = torch.randn(256, 128, device="cuda").bfloat16()
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        y = ag.Linear.apply(x, lin.weight, None, None, None, True).sum() + ag.QKVLinear.apply(x, wq, wk, wv).float().sum()
+        y.backward()
+        pack_before, fused_before = ag.PACKS.get(lin.weight)[0], ag.QKV_PACKS.get((wq, wk, wv))[0]
+        opt.step()
+        pack, pack_t = ag.PACKS.get(lin.weight)
+        assert pack.data_ptr() == pack_before.data_ptr()                       # refreshed in place by the optimiser kernel, not re-packed
+        assert torch.equal(pack, lin.weight.detach().bfloat16()) and torch.equal(pack_t[:, :192], pack.t())
+        fused, fused_t = ag.QKV_PACKS.get((wq, wk, wv))
+        assert fused.data_ptr() == fused_before.data_ptr()
+        assert torch.equal(fused, torch.cat([wq, wk, wv]).detach().bfloat16()) and torch.equal(fused_t[:, :192], fused.t())
+    with torch.no_grad():
+        lin.weight.mul_(2.0)                                                     # any other in-place write: the pack is rebuilt from the f32 values
+    assert torch.equal(ag.PACKS.get(lin.weight)[0], lin.weight.detach().bfloat16())
+
+
 def test_hip_adam_late_starting_parameter_keeps_its_own_step_count():
     """torch.optim.Adam counts steps per parameter: one whose grad was None on earlier steps (a projector whose modality was
     dropped under `zero_grad(set_to_none=True)`, model.py:133-141) starts its bias corrections at 1 when it first gets a gradient."""
