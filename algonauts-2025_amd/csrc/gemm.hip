@@ -535,6 +535,9 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   // 192 tiles) run faster on 128^2 tiles (60 -> 47 us; profiles/r02_o_gemm_shapes.txt); with K > 2048 or N > 2048 the 256^2 tiles'
   // higher operand reuse wins back more than the idle CUs cost.
   if (use_big && t256 < 512 && t128 >= 512 && d->K <= 2048 && d->N <= 2048) use_big = 0;
+  // 256-wide tiles that hang a quarter or more over the edge of a narrow C (dQ = dS K per head: N = 384 fills 1.5 of them) lose more MFMA
+  // work than 128^2 tiles cost: batched 1024 x 384 x 1024, 128 batches: 246 -> 204 us
+  if (use_big && t128 >= 512 && (double)t128 * 128 * 128 * 1.25 <= (double)t256 * 256 * 256) use_big = 0;
   if (d->tile_hint == 1) use_big = 0;
   if (d->tile_hint == 2) use_big = 1;
   if (d->trans_ab) {
