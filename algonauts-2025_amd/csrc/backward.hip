@@ -146,6 +146,48 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const T* __restrict__ a, c
   }
 }
 
+// One pass over an incoming f32 gradient dy [M, N] for everything a Linear / FeedForward backward needs from it: the bias gradient
+// sum_m dy, the res_scale gradient sum_m dy * res, and the bf16 copy the dgrad / wgrad GEMMs read (three separate passes before).
+__global__ __launch_bounds__(256) void colsum_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t M, int64_t N, int64_t ld,
+                                                          float* __restrict__ sum_a, float* __restrict__ sum_ab, unsigned short* __restrict__ a_bf16,
+                                                          int64_t ld_bf16) {
+  constexpr int U = 8;
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (n >= N) return;
+  const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+  const int64_t m0 = (int64_t)blockIdx.y * per, m1 = (m0 + per < M) ? m0 + per : M;
+  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+  auto take = [&](int64_t m, const float4 v, const float4 w) {
+    sa.x += v.x; sa.y += v.y; sa.z += v.z; sa.w += v.w;
+    if (b) { sb.x += v.x * w.x; sb.y += v.y * w.y; sb.z += v.z * w.z; sb.w += v.w * w.w; }
+    if (a_bf16) {
+      u16x4_t o;
+      o[0] = f32_to_bf16(v.x); o[1] = f32_to_bf16(v.y); o[2] = f32_to_bf16(v.z); o[3] = f32_to_bf16(v.w);
+      *(u16x4_t*)(a_bf16 + m * ld_bf16 + n) = o;
+    }
+  };
+  int64_t m = m0;
+  for (; m + U <= m1; m += U) {
+    float4 v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = load_nt_f4(a + (m + u) * ld + n);
+    if (b) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = load_nt_f4(b + (m + u) * ld + n);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) take(m + u, v[u], b ? w[u] : v[u]);
+  }
+  for (; m < m1; ++m) {
+    const float4 v = load_nt_f4(a + m * ld + n);
+    take(m, v, b ? load_nt_f4(b + m * ld + n) : v);
+  }
+  if (m0 < m1) {
+    if (sum_a) { atomicAdd(sum_a + n, sa.x); atomicAdd(sum_a + n + 1, sa.y); atomicAdd(sum_a + n + 2, sa.z); atomicAdd(sum_a + n + 3, sa.w); }
+    if (sum_ab) { atomicAdd(sum_ab + n, sb.x); atomicAdd(sum_ab + n + 1, sb.y); atomicAdd(sum_ab + n + 2, sb.z); atomicAdd(sum_ab + n + 3, sb.w); }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scalenorm_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                             const float* __restrict__ g, float gain_scale, float eps, int64_t rows,
@@ -544,6 +586,27 @@ extern "C" int tribe_colsum_fwd(const void* a, int32_t a_dtype, const float* b, 
   if (a_dtype == TRIBE_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)a, b, M, N, ld, out);
   else if (a_dtype == TRIBE_BF16) hipLaunchKernelGGL(colsum_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)a, b, M, N, ld, out);
   else TRIBE_REQUIRE(false, "tribe_colsum_fwd: dtype must be f32 or bf16");
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tribe_colsum_cast_fwd(const float* a, const float* b, int64_t M, int64_t N, int64_t ld, float* sum_a, float* sum_ab,
+                                     uint16_t* a_bf16, int64_t ld_bf16, void* stream) {
+  TRIBE_REQUIRE(a && (sum_a || sum_ab || a_bf16), "tribe_colsum_cast_fwd: nothing to compute");
+  TRIBE_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld >= N && ld % 4 == 0 && ((uintptr_t)a % 16) == 0 && (!b || ((uintptr_t)b % 16) == 0) && (!sum_ab || b),
+                "tribe_colsum_cast_fwd: needs N %% 4 == 0, 16-byte aligned rows and b for sum_ab");
+  TRIBE_REQUIRE(!a_bf16 || (ld_bf16 >= N && ld_bf16 % 4 == 0 && ((uintptr_t)a_bf16 % 8) == 0), "tribe_colsum_cast_fwd: bad bf16 output");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipSuccess;
+  if (sum_a) e = hipMemsetAsync(sum_a, 0, (size_t)N * sizeof(float), s);
+  if (e == hipSuccess && sum_ab) e = hipMemsetAsync(sum_ab, 0, (size_t)N * sizeof(float), s);
+  if (e != hipSuccess) { tribe_set_error("tribe_colsum_cast_fwd: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+  const int64_t col_blocks = (N / 4 + 255) / 256;
+  int64_t slices = (8192 + col_blocks - 1) / col_blocks;
+  if (slices > (M + 127) / 128) slices = (M + 127) / 128;
+  if (slices < 1) slices = 1;
+  if (slices > 65535) slices = 65535;
+  hipLaunchKernelGGL(colsum_cast_kernel, dim3((unsigned)col_blocks, (unsigned)slices), dim3(256), 0, s, a, b, M, N, ld, sum_a, sum_ab, a_bf16, ld_bf16);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

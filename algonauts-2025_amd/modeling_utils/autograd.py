@@ -62,6 +62,21 @@ def transpose_bf16(x: torch.Tensor, Z: int, R: int, Cc: int, s_z: int, s_r: int,
     return out
 
 
+def grad_sums_and_cast(dy: torch.Tensor, M: int, N: int, res: torch.Tensor | None = None, want_sum: bool = False,
+                       want_bf16: bool = True) -> tuple[torch.Tensor | None, torch.Tensor | None, torch.Tensor | None]:
+    """One pass over an incoming f32 gradient dy [M, N]: (column sums or None, column sums of dy * res or None, bf16 copy or None) --
+    the bias gradient, the res_scale gradient and the GEMM operand of a Linear / FeedForward backward (tribe_colsum_cast_fwd)."""
+    dev = dy.device
+    if dy.dtype != torch.float32 or N % 4:
+        return (colsum(dy, M, N) if want_sum else None, colsum(dy, M, N, b=res) if res is not None else None,
+                cast_bf16(dy) if want_bf16 else None)
+    sa = torch.empty(N, dtype=torch.float32, device=dev) if want_sum else None
+    sab = torch.empty(N, dtype=torch.float32, device=dev) if res is not None else None
+    bf = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    check(lib().tribe_colsum_cast_fwd(dy.data_ptr(), ops._p(res), M, N, N, ops._p(sa), ops._p(sab), ops._p(bf), N, _s()), "tribe_colsum_cast_fwd")
+    return sa, sab, bf
+
+
 def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, M: int, N: int, K: int, ld_dy: int, ld_x: int) -> None:
     """dw[n, k] = sum_m dy[m, n] x[m, k]  (dy bf16 [M, ld_dy >= N], x bf16 [M, ld_x >= K], dw f32 [N, K]): the weight gradient of a Linear.
     Shapes the 256^2 kernel covers go through its transposed-operand form (desc.trans_ab: dy and x are read as they lie, the LDS reads
@@ -163,11 +178,10 @@ class Linear(torch.autograd.Function):
             else:
                 dres = torch.empty_like(res)
                 check(lib().tribe_scale_cols_fwd(dy.data_ptr(), ops._p(res_scale), M, N, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
-            if res_scale is not None:
-                drs = colsum(dy, M, N, b=res)
+        # bias gradient, res_scale gradient and the bf16 GEMM operand from ONE pass over dy
+        db, drs, dpre = grad_sums_and_cast(dy, M, N, res=res if (res is not None and res_scale is not None) else None, want_sum=ctx.has_b)
         _, wt = PACKS.get(w)  # [K, N_pad64]
         Np = wt.shape[1]
-        dpre = cast_bf16(dy)
         if Np != N:
             dpre = torch.nn.functional.pad(dpre, (0, Np - N))  # zero K-padding for the dgrad GEMM (N % 64 != 0 only)
         dx = torch.empty(M, K, dtype=x.dtype, device=x.device)   # x is bf16: autograd would cast an f32 gradient in a pass of its own
@@ -176,9 +190,6 @@ class Linear(torch.autograd.Function):
         dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
         wgrad(dpre, x, dw, M, N, K, Np, K)
         dw = dw[:, : w.shape[1]] if w.shape[1] != K else dw
-        db = colsum(dpre, M, Np) if ctx.has_b else None   # over the padded row (stride Np); the zero pad columns are dropped below
-        if Np != N and db is not None:
-            db = db[:N]
         return dx, dw, db, dres, drs, None, None
 
 
@@ -293,9 +304,7 @@ class FeedForward(torch.autograd.Function):
         else:
             dres = torch.empty_like(res)
             check(lib().tribe_scale_cols_fwd(dout.data_ptr(), ops._p(res_scale), M, D, dres.data_ptr(), _s()), "tribe_scale_cols_fwd")
-        drs = colsum(dout, M, D, b=res) if res_scale is not None else None
-        db2 = colsum(dout, M, D)
-        dob = cast_bf16(dout)                                   # [M, D]
+        db2, drs, dob = grad_sums_and_cast(dout, M, D, res=res if res_scale is not None else None, want_sum=True)   # one pass over dout
         _, w2t = PACKS.get(w2)                                  # [Fh, D]
         dpre = torch.empty(M, Fh, dtype=torch.bfloat16, device=x.device)
         _gemm(dob, w2t, dpre, lda=D, ldb=D, ldc=Fh, M=M, N=Fh, K=D, act=_lib.ACT_GELU_BWD, aux=pre)   # dh * gelu'(pre)

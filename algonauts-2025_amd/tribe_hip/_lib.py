@@ -208,6 +208,7 @@ SIGNATURES = {
     "tribe_adaptive_avg_pool_bwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
     "tribe_rowsum_scatter": (C.c_int, [vp, i64, i64, i64, vp, vp, vp]),
     "tribe_slab_scatter_sum": (C.c_int, [vp, i64, i64, vp, vp, vp]),
+    "tribe_colsum_cast_fwd": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, vp, i64, vp]),
     "tribe_scale_cols_fwd": (C.c_int, [vp, vp, i64, i64, vp, vp]),
     "tribe_pearson_loss_bwd": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, vp, i32, vp, vp, vp]),
     "tribe_lse_rows_fwd": (C.c_int, [vp, i64, i64, vp, vp, vp]),

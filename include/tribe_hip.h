@@ -438,6 +438,11 @@ int tribe_mse_bwd(const float* pred, const float* truth, int64_t n, const float*
 int tribe_adaptive_avg_pool_bwd(const float* dy, int64_t rows, int64_t T_in, int64_t T_out, float* dx, void* stream);
 /* out[idx[b], v] += sum_t x[b, v, t]   (SubjectLayers bias gradient) */
 int tribe_rowsum_scatter(const float* x, int64_t B, int64_t V, int64_t T, const int64_t* idx, float* out, void* stream);
+/* One pass over a gradient dy = a f32 [M, N] (row stride ld): sum_a[n] = sum_m a[m, n] (bias gradient), sum_ab[n] = sum_m a[m, n] b[m, n]
+ * (res_scale gradient: b = the residual input), a_bf16 = bf16(a) with row stride ld_bf16 (the GEMM operand of dgrad / wgrad).  Any of the
+ * three outputs may be NULL; N % 4 == 0.  Replaces `grad.sum(0)`, `(grad * res).sum(0)` and the cast of autograd's Linear backward. */
+int tribe_colsum_cast_fwd(const float* a, const float* b, int64_t M, int64_t N, int64_t ld, float* sum_a, float* sum_ab, uint16_t* a_bf16,
+                          int64_t ld_bf16, void* stream);
 /* dst[idx[b], :] += src[b, :] for b = 0 .. B-1 in that order (deterministic; no atomics): src f32 [B, n], dst f32 [S, n], n % 4 == 0.
  * SubjectLayers weight gradient: the per-sample products x_b^T dy_b of one batched GEMM summed into their subject's slab
  * (modeling_utils/models/common.py:60-76 is the forward it differentiates). */

@@ -193,6 +193,23 @@ def test_column_sums(M, N, dtype, with_b):
     torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-3 * M**0.5)
 
 
+@pytest.mark.parametrize("M,N,with_b", [(16384, 3072, True), (1000, 768, False), (77, 100, True)])
+def test_gradient_sums_and_cast_in_one_pass(M, N, with_b):
+    """tribe_colsum_cast_fwd: bias gradient, res_scale gradient and the bf16 GEMM operand from one pass over an f32 gradient."""
+    from modeling_utils.autograd import grad_sums_and_cast
+
+    g = torch.Generator().manual_seed(15)
+    dy = torch.randn(M, N, generator=g)
+    res = torch.randn(M, N, generator=g) if with_b else None
+    sa, sab, bf = grad_sums_and_cast(dy.cuda(), M, N, res=res.cuda() if with_b else None, want_sum=True)
+    torch.testing.assert_close(sa.cpu().double(), dy.double().sum(0), rtol=1e-4, atol=2e-3 * M**0.5)
+    if with_b:
+        torch.testing.assert_close(sab.cpu().double(), (dy.double() * res.double()).sum(0), rtol=1e-4, atol=2e-3 * M**0.5)
+    else:
+        assert sab is None
+    assert torch.equal(bf.cpu(), dy.bfloat16())
+
+
 def test_slab_scatter_sum_is_the_ordered_sum():
     """tribe_slab_scatter_sum: dst[idx[b]] += src[b] for b in order == the same loop on the host, bit for bit."""
     from tribe_hip._lib import check, lib
