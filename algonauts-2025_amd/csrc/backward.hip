@@ -299,6 +299,36 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short* 
     ds[i] = (i < T) ? f32_to_bf16(bf16_to_f32(p[i]) * (dp[i] - delta) * scale) : (unsigned short)0;
 }
 
+// the same product with the row in registers (T = 256 NV, no padding): P and dP are read once, 8- / 16-byte accesses
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_reg_kernel(const unsigned short* __restrict__ P, const float* __restrict__ dP, int64_t rows,
+                                                              int64_t ld_p, int64_t ld_dp, float scale, unsigned short* __restrict__ dS, int64_t ld_ds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const unsigned short* p = P + row * ld_p;
+  const float* dp = dP + row * ld_dp;
+  float4 pv[NV], dv[NV];
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const u16x4_t q = __builtin_nontemporal_load((const u16x4_t*)(p + (lane + 64 * j) * 4));
+    pv[j] = make_float4(bf16_to_f32(q[0]), bf16_to_f32(q[1]), bf16_to_f32(q[2]), bf16_to_f32(q[3]));
+    dv[j] = load_nt_f4(dp + (lane + 64 * j) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) delta += (pv[j].x * dv[j].x + pv[j].y * dv[j].y) + (pv[j].z * dv[j].z + pv[j].w * dv[j].w);
+  delta = wave_sum(delta);
+  unsigned short* ds = dS + row * ld_ds;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    u16x4_t o;
+    o[0] = f32_to_bf16(pv[j].x * (dv[j].x - delta) * scale); o[1] = f32_to_bf16(pv[j].y * (dv[j].y - delta) * scale);
+    o[2] = f32_to_bf16(pv[j].z * (dv[j].z - delta) * scale); o[3] = f32_to_bf16(pv[j].w * (dv[j].w - delta) * scale);
+    *(u16x4_t*)(ds + (lane + 64 * j) * 4) = o;
+  }
+}
+
 // dpred = gs * 2 (p - t) / n.  HBM-bound: 12 bytes per element; float4 streams, two pairs in flight per lane.
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
                                                       const float* __restrict__ gs, float* __restrict__ dp, int vec) {
@@ -643,8 +673,15 @@ extern "C" int tribe_softmax_bwd(const uint16_t* P, const float* dP, int64_t row
                                  float scale, uint16_t* dS, int64_t ld_ds, void* stream) {
   TRIBE_REQUIRE(P && dP && dS, "tribe_softmax_bwd: null pointer");
   TRIBE_REQUIRE(rows > 0 && T > 0 && T_pad >= T && ld_p >= T && ld_dp >= T && ld_ds >= T_pad, "tribe_softmax_bwd: bad shape");
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, dP, rows, T, T_pad, ld_p,
-                     ld_dp, scale, dS, ld_ds);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  const bool reg = T_pad == T && T % 256 == 0 && T <= 2048 && ld_p % 4 == 0 && ld_dp % 4 == 0 && ld_ds % 4 == 0 && ((uintptr_t)P % 8) == 0 &&
+                   ((uintptr_t)dP % 16) == 0 && ((uintptr_t)dS % 8) == 0;
+  if (reg && T == 256) hipLaunchKernelGGL(softmax_bwd_reg_kernel<1>, grid, dim3(256), 0, st, P, dP, rows, ld_p, ld_dp, scale, dS, ld_ds);
+  else if (reg && T == 512) hipLaunchKernelGGL(softmax_bwd_reg_kernel<2>, grid, dim3(256), 0, st, P, dP, rows, ld_p, ld_dp, scale, dS, ld_ds);
+  else if (reg && T == 1024) hipLaunchKernelGGL(softmax_bwd_reg_kernel<4>, grid, dim3(256), 0, st, P, dP, rows, ld_p, ld_dp, scale, dS, ld_ds);
+  else if (reg && T == 2048) hipLaunchKernelGGL(softmax_bwd_reg_kernel<8>, grid, dim3(256), 0, st, P, dP, rows, ld_p, ld_dp, scale, dS, ld_ds);
+  else hipLaunchKernelGGL(softmax_bwd_kernel, grid, dim3(256), 0, st, P, dP, rows, T, T_pad, ld_p, ld_dp, scale, dS, ld_ds);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

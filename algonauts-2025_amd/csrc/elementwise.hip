@@ -567,6 +567,39 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
   for (int64_t i = lane; i < T_pad; i += 64) p[i] = (i < T) ? f32_to_bf16(__expf(s[i] - m) * inv) : (unsigned short)0;
 }
 
+// the same softmax with the row in registers (T = 256 NV, no padding): S is read once with 16-byte loads, exp is evaluated once per
+// score (the walk above evaluates it twice and moves 4 / 2 bytes per lane and instruction), P leaves as 8-byte stores
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_reg_kernel(const float* __restrict__ S, int64_t R, int64_t ld_s, unsigned short* __restrict__ P,
+                                                          int64_t ld_p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* s = S + row * ld_s;
+  float4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = load_nt_f4(s + (lane + 64 * j) * 4);
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) m = fmaxf(m, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j].x = __expf(v[j].x - m); v[j].y = __expf(v[j].y - m); v[j].z = __expf(v[j].z - m); v[j].w = __expf(v[j].w - m);
+    sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  unsigned short* p = P + row * ld_p;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    u16x4_t o;
+    o[0] = f32_to_bf16(v[j].x * inv); o[1] = f32_to_bf16(v[j].y * inv); o[2] = f32_to_bf16(v[j].z * inv); o[3] = f32_to_bf16(v[j].w * inv);
+    *(u16x4_t*)(p + (lane + 64 * j) * 4) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // adaptive average pool along the last axis: x f32 [rows, T_in] -> y [rows, T_out]
 // ---------------------------------------------------------------------------------
@@ -856,7 +889,13 @@ extern "C" int tribe_projector_zero_fwd(int64_t BT, int64_t T, int64_t N_out, fl
 // ---- internal helpers used by encoder.hip (same shared object, not part of the public ABI) ----
 int tribe_internal_softmax(const float* S, int64_t R, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, S, R, T, ld_s, P, T_pad, ld_p);
+  const dim3 grid((unsigned)((R + 3) / 4));
+  const bool reg = T_pad == T && T % 256 == 0 && T <= 2048 && ld_s % 4 == 0 && ld_p % 4 == 0 && ((uintptr_t)S % 16) == 0 && ((uintptr_t)P % 8) == 0;
+  if (reg && T == 256) hipLaunchKernelGGL(softmax_reg_kernel<1>, grid, dim3(256), 0, stream, S, R, ld_s, P, ld_p);
+  else if (reg && T == 512) hipLaunchKernelGGL(softmax_reg_kernel<2>, grid, dim3(256), 0, stream, S, R, ld_s, P, ld_p);
+  else if (reg && T == 1024) hipLaunchKernelGGL(softmax_reg_kernel<4>, grid, dim3(256), 0, stream, S, R, ld_s, P, ld_p);
+  else if (reg && T == 2048) hipLaunchKernelGGL(softmax_reg_kernel<8>, grid, dim3(256), 0, stream, S, R, ld_s, P, ld_p);
+  else hipLaunchKernelGGL(softmax_kernel, grid, dim3(256), 0, stream, S, R, T, ld_s, P, T_pad, ld_p);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }

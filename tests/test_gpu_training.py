@@ -79,7 +79,7 @@ def test_autograd_blocks_vs_torch():
     torch.testing.assert_close(pg.grad.cpu(), pt.grad, rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("B,T,h,d", [(2, 128, 2, 64), (1, 192, 3, 384), (2, 70, 2, 64)])
+@pytest.mark.parametrize("B,T,h,d", [(2, 128, 2, 64), (1, 192, 3, 384), (2, 70, 2, 64), (1, 256, 2, 64), (1, 1024, 1, 128)])
 def test_attention_backward_with_and_without_explicit_transposes(B, T, h, d):
     """T % 64 == 0 sends dV = P^T dO and dK = dS^T Q through the transposed-operand GEMM (batched over (sequence, head), strided head
     slices as operands); T = 70 keeps the explicit transposes.  Gradients of the fused qkv buffer vs torch."""
