@@ -293,6 +293,20 @@ def embedding(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def dwconv_ln_swish(x: torch.Tensor, B: int, T: int, w_kc: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float) -> torch.Tensor:
+    """Causal depthwise Conv1d over time (left pad K - 1, no bias) + LayerNorm over channels + swish (Wav2Vec2BertConvolutionModule,
+    modeling_wav2vec2_bert.py:214-222): x bf16 [B*T, C], w_kc f32 [K, C] (tap-major) -> bf16 [B*T, C]."""
+    _cuda(x, torch.bfloat16, "x")
+    _cuda(w_kc, torch.float32, "w_kc")
+    K, Cc = w_kc.shape
+    if x.shape != (B * T, Cc):
+        raise ValueError(f"dwconv_ln_swish: x must be [{B * T}, {Cc}], got {tuple(x.shape)}")
+    y = torch.empty_like(x)
+    check(lib().tribe_dwconv_ln_swish_fwd(x.data_ptr(), B, T, Cc, K, w_kc.data_ptr(), _cuda(ln_w, torch.float32, "ln_w").data_ptr(),
+                                          _cuda(ln_b, torch.float32, "ln_b").data_ptr(), eps, y.data_ptr(), _stream()), "tribe_dwconv_ln_swish_fwd")
+    return y
+
+
 def segment_mean(x: torch.Tensor, B: int, T: int, start: torch.Tensor | None, length: torch.Tensor | None) -> torch.Tensor:
     _cuda(x, torch.float32, "x")
     dim = x.shape[-1]

@@ -262,6 +262,22 @@ def test_rope3d_tables_match_transformers():
     torch.testing.assert_close(q * cos + rot * sin, want, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,T,Cc,K", [(2, 300, 1024, 31), (1, 7, 128, 31), (3, 50, 256, 5), (1, 20, 2048, 31)])
+def test_depthwise_conv_layernorm_swish(B, T, Cc, K):
+    """tribe_dwconv_ln_swish_fwd vs torch (causal depthwise Conv1d, LayerNorm over channels, SiLU): the 8-steps-per-workgroup kernel
+    (C <= 1024, K <= 31; ragged last tile at T = 300 / 7 / 50, K = 5 leaves 26 zero tap slots) and the one-row kernel (C = 2048)."""
+    from tribe_hip import ops
+
+    g = torch.Generator().manual_seed(16)
+    x = bf(torch.randn(B, T, Cc, generator=g))
+    w = torch.randn(K, Cc, generator=g) / K**0.5
+    ln_w, ln_b = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    conv = torch.nn.functional.conv1d(torch.nn.functional.pad(x.transpose(1, 2), (K - 1, 0)), w.t().unsqueeze(1), groups=Cc).transpose(1, 2)
+    want = torch.nn.functional.silu(torch.nn.functional.layer_norm(conv, (Cc,), ln_w, ln_b, 1e-5))
+    got = ops.dwconv_ln_swish(x.reshape(B * T, Cc).cuda().bfloat16(), B, T, w.cuda(), ln_w.cuda(), ln_b.cuda(), 1e-5).float().cpu().view(B, T, Cc)
+    torch.testing.assert_close(got, want, rtol=2**-7, atol=2e-2)
+
+
 def _tiny_w2vbert(hidden=128, heads=2, layers=2, inter=256):
     from transformers import Wav2Vec2BertConfig, Wav2Vec2BertModel
 
