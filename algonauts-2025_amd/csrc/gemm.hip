@@ -124,6 +124,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
 
   // which: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1
   auto stage = [&](int which, int buf, int kt) {
+#ifdef TRIBE_ABL_NO_STAGE   // ablation build (scripts/gemm_ablation.py): no LDS-DMA, the K loop computes on whatever LDS holds
+    return;
+#endif
     char* base = smem + buf * BUF_BYTES;
     const int64_t koff_a = TN ? (int64_t)kt * BK * g.lda : (int64_t)kt * BK;   // K runs along the rows of a transposed operand
     const int64_t koff_b = TN ? (int64_t)kt * BK * g.ldb : (int64_t)kt * BK;
@@ -150,6 +153,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const int b_rd = A_BYTES + (wc * 64 + frow) * 128;   // + nh*4096 + j*2048 + coff
 
   bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+#ifdef TRIBE_ABL_NO_LDSREAD
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      fa[i][k] = bf16x8_t{(short)(0x3c00 + lane), (short)0x3f80, (short)(0xbf00 + i), (short)0x3e00, (short)0xbe80, (short)0x3f00, (short)(0x3d00 + k), (short)0xbd00};
+      if (i < 2) { fb0[i][k] = fa[i][k]; fb1[i][k] = fa[i][k]; }
+    }
+#endif
 
   // TN fragment reads: lane i of a 16-lane group supplies k-row 4 fq + (i >> 2) (and + 16) of the k-step and 4 of the fragment's 16
   // tile rows; after the hardware transpose lane (frow, fq) holds k = {4 fq .. + 3, 16 + 4 fq .. + 3} of tile row frow, for A and B alike.
@@ -170,6 +182,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
     return f;
   };
 
+#ifdef TRIBE_ABL_NO_LDSREAD   // ablation build: fragments stay what the prologue put in the registers (opaque to the optimiser)
+#define TRIBE_LDS_A(base, MH) _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[i][0]), "+v"(fa[i][1])); }
+#define TRIBE_LDS_B(base, NH, FB) _Pragma("unroll") for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(FB[j][0]), "+v"(FB[j][1])); }
+#else
 #define TRIBE_LDS_A(base, MH)                                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
     if (TN) {                                                                                  \
@@ -190,6 +206,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
       FB[j][1] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff1);           \
     }                                                                                          \
   }
+#endif
+#ifdef TRIBE_ABL_NO_MFMA   // ablation build: the fragments are consumed by an empty asm instead of the matrix pipe
+#define TRIBE_MMA(MH, NH, FB)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(fa[i][0]), "v"(fa[i][1])); } \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(FB[j][0]), "v"(FB[j][1])); }
+#else
 #define TRIBE_MMA(MH, NH, FB)                                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
@@ -198,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
     acc[(MH) * 4 + i][(NH) * 2 + j] =                                                          \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], FB[j][1], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
   }
+#endif
 // The fragment reads are retired BEFORE the barrier: the two wave groups (wr = 0 / 1 = the two waves of every
 // SIMD) run one barrier apart, so while one group sits in this wait the other group's MFMA cluster owns the
 // matrix pipe, and at every barrier all LDS reads issued so far are complete (restaging is then hazard-free).
