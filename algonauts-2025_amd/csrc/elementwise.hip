@@ -354,7 +354,10 @@ void launch_rowstat_norm(const float* x, int64_t rows, int64_t dim, const float*
                          hipStream_t s) {
   dim3 grid((unsigned)((rows + 3) / 4));
   const int nv = (int)((dim / 4 + 63) / 64);
-  const bool aligned = ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && (!b || ((uintptr_t)b % 16) == 0);
+  // the register-resident kernel stores float4 / u16x4 / packed fp8x4 per lane: y needs 16 / 8 / 4-byte alignment (row pitch = dim elements)
+  const uintptr_t y_align = OUT_BF16 == 0 ? 16 : (OUT_BF16 == 1 ? 8 : 4);
+  const bool aligned = ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && (!b || ((uintptr_t)b % 16) == 0) && ((uintptr_t)y % y_align) == 0 &&
+                       dim % 4 == 0;
 #define TRIBE_RSN(NV) hipLaunchKernelGGL((rowstat_norm_reg_kernel<OUT_BF16, LAYERNORM, NV>), grid, dim3(256), 0, s, x, rows, dim, w, b, eps, y, q_inv_scale)
   if (aligned && nv <= 4) TRIBE_RSN(4);
   else if (aligned && nv <= 6) TRIBE_RSN(6);

@@ -153,7 +153,7 @@ inline EncPlan enc_plan(const tribe_encoder_desc* d) {
   p.big_bytes = align256((size_t)p.M * wide * 2);
   p.attn_bytes = align256(tribe_attention_workspace_bytes(d->B, d->T, d->heads, d->dim_head));
   p.fuse_norm = d->dim % 256 == 0 && p.inner % 256 == 0 && d->ff_inner % 256 == 0;
-  p.norm_bytes = p.fuse_norm ? align256((size_t)p.M * (d->dim / 64 + 1) * 4) : 0;   // partial sums of squares + the row factors
+  p.norm_bytes = p.fuse_norm ? align256((size_t)p.M * (d->dim / 32 + 1) * 4) : 0;   // partial sums of squares (<= dim / 32 slots per row, by the producer's tile) + the row factors
   return p;
 }
 inline int enc_validate(const tribe_encoder_desc* d) {
@@ -191,9 +191,9 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
   uint16_t* ao = big + (size_t)M * 3 * inner;  // [M, inner]
   uint16_t* hbuf = big;                        // [M, ff_inner]  (qkv/ao are dead by then)
   void* attn_ws = (char*)workspace + p.xn_bytes + p.big_bytes;
-  float* ssq = (float*)((char*)workspace + p.xn_bytes + p.big_bytes + p.attn_bytes);   // [M, dim / 64] partial sums of squares
-  float* rowf = ssq + (size_t)M * (dim / 64);                                          // [M] ScaleNorm factors
-  const int64_t n_part = dim / 64;
+  float* ssq = (float*)((char*)workspace + p.xn_bytes + p.big_bytes + p.attn_bytes);   // [M, n_part] partial sums of squares
+  float* rowf = ssq + (size_t)M * (dim / 32);                                          // [M] ScaleNorm factors
+  int64_t n_part = dim / 64;   // slots per row the LAST producer wrote (one per wave column group of its tile: tribe_gemm_sumsq_slots)
   const float scale = 1.0f / sqrtf((float)d->dim_head);
   // With whole 256-column tiles the pre-norms are folded into the GEMMs: the GEMM that writes x also leaves bf16(x) in `xn` and
   // the per-row partial sums of squares; a [M]-sized kernel turns them into the ScaleNorm factors; the next GEMM reads the raw
@@ -242,7 +242,12 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.C = x; g.ldc = dim; g.c_dtype = TRIBE_F32;
     g.res = x; g.ldres = dim; g.res_scale = L.attn_res_scale;
     g.role = TRIBE_ROLE_OUT_PROJ;
-    if (fuse) { g.c_bf16 = xn; g.ld_c_bf16 = dim; g.row_sumsq = ssq; g.ld_row_sumsq = n_part; }
+    if (fuse) {
+      g.c_bf16 = xn; g.ld_c_bf16 = dim; g.row_sumsq = ssq;
+      n_part = tribe_gemm_sumsq_slots(&g);
+      TRIBE_REQUIRE(n_part > 0 && n_part <= dim / 32, "tribe_encoder_fwd: unexpected row_sumsq slot count %lld", (long long)n_part);
+      g.ld_row_sumsq = n_part;
+    }
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     // ---- feed-forward block: x = W2 gelu(W1 norm(x) + b1) + b2 + x * residual_scale ----
@@ -269,7 +274,12 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.res = x; g.ldres = dim; g.res_scale = L.ff_res_scale;
     g.role = TRIBE_ROLE_FF2;
     have_factors = fuse && l + 1 < d->depth;   // the next layer's QKV takes the raw bf16(x) + factors
-    if (have_factors) { g.c_bf16 = xn; g.ld_c_bf16 = dim; g.row_sumsq = ssq; g.ld_row_sumsq = n_part; }
+    if (have_factors) {
+      g.c_bf16 = xn; g.ld_c_bf16 = dim; g.row_sumsq = ssq;
+      n_part = tribe_gemm_sumsq_slots(&g);
+      TRIBE_REQUIRE(n_part > 0 && n_part <= dim / 32, "tribe_encoder_fwd: unexpected row_sumsq slot count %lld", (long long)n_part);
+      g.ld_row_sumsq = n_part;
+    }
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
   }

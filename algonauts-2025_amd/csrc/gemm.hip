@@ -66,9 +66,20 @@ constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // 128 KiB
 // changes is the LDS image (per half-tile [64 k][128 out] rows of 256 bytes, 16-byte chunks XOR-swizzled by (k & 7) << 1 on the source
 // side) and the fragment reads (two ds_read_b64_tr_b16 per fragment instead of one ds_read_b128: the hardware transposes; A and B use
 // the same k order inside an MFMA, so the sum is unchanged).  Replaces the explicit bf16 transposes of the wgrad operands.
-template <int OUT_BF16, int ROLE, int TN = 0>
+//
+// NB = tile columns / 64 (round 3): the tile is 256 x (64 NB), a wave owns 128 x (16 NB), NB accumulator columns of 16.  NB = 4 is
+// the 256 x 256 kernel; NB = 3 (256 x 192) exists for grids whose 256-wide tiles quantise badly on 256 CUs -- the BASELINE config at
+// B = 4 has M = 4096: QKV 576 tiles (2.25 rounds), out-proj / FF2 192 tiles (0.75 of the chip) become 768 / 256 / 256.  The B tile is
+// staged as NB LDS-DMA loads per wave (rows in tile order), all read in phase A and restaged in phase B, so the counted waits leave
+// 4 + NB loads in flight.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int OUT_BF16, int ROLE, int TN = 0, int NB = 4>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
-  using namespace big;
+  static_assert(NB >= 2 && NB <= 4 && (!TN || NB == 4), "tile columns: 128, 192 or 256; transposed operands: 256 only");
+  constexpr int BM = big::BM, BN = 64 * NB, A_BYTES = big::A_BYTES, BUF_BYTES = A_BYTES + BN * BK * 2;
+  constexpr int WN = 16 * NB;                      // columns per wave
+  constexpr int VM_STEADY = NB == 4 ? TRIBE_GEMM_VM_STEADY : 4 + NB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -85,14 +96,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const unsigned short* A = (const unsigned short*)g.A + (g.gather_a ? b1g : b1) * g.sA1 + b0 * g.sA0;
   const unsigned short* B = (const unsigned short*)g.B + (g.gather_b ? b1g : b1) * g.sB1 + b0 * g.sB0;
 
-  // ---- staging: half-tile = the 128 tile rows read in one phase; each wave moves 2 slabs of 8 rows ----
-  //   A half h: rows {wr'*128 + h*64 + 0..63, wr' = 0,1};   slab j of this wave: row0 = j*128 + h*64 + wave*8
-  //   B half h: rows {wc'*64 + h*32 + 0..31, wc' = 0..3};   slab j of this wave: row0 = (2j + (wave>>2))*64 + h*32 + (wave&3)*8
+  // ---- staging: each LDS-DMA instruction of a wave moves a slab of 8 tile rows x 128 bytes (row r of an operand tile at r * 128) ----
+  //   A half h = the 128 tile rows phase h reads: {wr' * 128 + h * 64 + 0..63, wr' = 0, 1}; slab j of this wave: row0 = j * 128 + h * 64 + wave * 8
+  //   B: slab q (0 .. NB-1) of this wave: row0 = q * 64 + wave * 8 (TN: the two half images of the round-2 layout, see below)
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ srow;  // swizzle on the SOURCE chunk (row & 7 == srow for every slab)
+#ifdef TRIBE_ABL_SAME_TILE   // ablation build: every workgroup streams the operand panels of tile (0, 0) -> all L2 hits (results are wrong)
+#define m0 ((int64_t)0)
+#define n0 ((int64_t)0)
+#endif
   const unsigned short* a_src[2][2];
-  const unsigned short* b_src[2][2];
-  int a_lds[2][2], b_lds[2][2];  // wave-uniform LDS byte offsets of the slabs inside a K-tile buffer
+  const unsigned short* b_src[NB];
+  int a_lds[2][2], b_lds[NB];  // wave-uniform LDS byte offsets of the slabs inside a K-tile buffer
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -107,22 +122,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
         int64_t gm = m0 + (lc >> 3) * 128 + h * 64 + (lc & 7) * 8; gm = gm + 8 <= g.M ? gm : g.M - 8;   // clamp to the last whole chunk
         int64_t gn = n0 + (lc >> 2) * 64 + h * 32 + (lc & 3) * 8; gn = gn + 8 <= g.N ? gn : g.N - 8;
         a_src[h][j] = A + (int64_t)krow * g.lda + gm;
-        b_src[h][j] = B + (int64_t)krow * g.ldb + gn;
+        b_src[(2 * h + j) % NB] = B + (int64_t)krow * g.ldb + gn;
         a_lds[h][j] = h * 16384 + piece * 1024;
-        b_lds[h][j] = A_BYTES + h * 16384 + piece * 1024;
+        b_lds[(2 * h + j) % NB] = A_BYTES + h * 16384 + piece * 1024;
       } else {
         const int ra = j * 128 + h * 64 + wave * 8;
-        const int rb = (2 * j + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8;
         int64_t gr = m0 + ra + srow; gr = gr < g.M ? gr : g.M - 1;  // clamp: edge rows re-read a valid row, stores are masked
-        int64_t gc = n0 + rb + srow; gc = gc < g.N ? gc : g.N - 1;
         a_src[h][j] = A + gr * g.lda + schunk * 8;
-        b_src[h][j] = B + gc * g.ldb + schunk * 8;
         a_lds[h][j] = ra * 128;
-        b_lds[h][j] = A_BYTES + rb * 128;
       }
     }
+  if (!TN) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int rb = q * 64 + wave * 8;
+      int64_t gc = n0 + rb + srow; gc = gc < g.N ? gc : g.N - 1;
+      b_src[q] = B + gc * g.ldb + schunk * 8;
+      b_lds[q] = A_BYTES + rb * 128;
+    }
+  }
 
-  // which: 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1
+#ifdef TRIBE_ABL_SAME_TILE
+#undef m0
+#undef n0
+#endif
+  // which: 0 = A half 0, 1 = the B tile (NB loads), 3 = A half 1
   auto stage = [&](int which, int buf, int kt) {
 #ifdef TRIBE_ABL_NO_STAGE   // ablation build (scripts/gemm_ablation.py): no LDS-DMA, the K loop computes on whatever LDS holds
     return;
@@ -135,37 +159,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
       __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][0] + koff_a), (lptr_t)(base + a_lds[h][0]), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h][1] + koff_a), (lptr_t)(base + a_lds[h][1]), 16, 0, 0);
     } else {
-      const int h = which == 2;
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][0] + koff_b), (lptr_t)(base + b_lds[h][0]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[h][1] + koff_b), (lptr_t)(base + b_lds[h][1]), 16, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+        __builtin_amdgcn_global_load_lds((gptr_t)(b_src[q] + koff_b), (lptr_t)(base + b_lds[q]), 16, 0, 0);
     }
   };
 
-  f32x4_t acc[8][4];
+  f32x4_t acc[8][NB];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
   const int coff0 = ((fq ^ (frow & 7)) << 4), coff1 = (((4 + fq) ^ (frow & 7)) << 4);
   const int a_rd = (wr * 128 + frow) * 128;            // + mh*8192 + i*2048 + coff
-  const int b_rd = A_BYTES + (wc * 64 + frow) * 128;   // + nh*4096 + j*2048 + coff
+  const int b_rd = A_BYTES + (wc * WN + frow) * 128;   // + j*2048 + coff
 
-  bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+  bf16x8_t fa[4][2], fb[NB][2];
 #ifdef TRIBE_ABL_NO_LDSREAD
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       fa[i][k] = bf16x8_t{(short)(0x3c00 + lane), (short)0x3f80, (short)(0xbf00 + i), (short)0x3e00, (short)0xbe80, (short)0x3f00, (short)(0x3d00 + k), (short)0xbd00};
-      if (i < 2) { fb0[i][k] = fa[i][k]; fb1[i][k] = fa[i][k]; }
+      if (i < NB) fb[i][k] = fa[i][k];
     }
 #endif
 
   // TN fragment reads: lane i of a 16-lane group supplies k-row 4 fq + (i >> 2) (and + 16) of the k-step and 4 of the fragment's 16
   // tile rows; after the hardware transpose lane (frow, fq) holds k = {4 fq .. + 3, 16 + 4 fq .. + 3} of tile row frow, for A and B alike.
-  // Fragment i of A's half image sits at logical chunks wr * 8 + 2 i (+ 1), fragment j of B's at wc * 4 + 2 j (+ 1).
+  // Fragment i of A's half image sits at logical chunks wr * 8 + 2 i (+ 1), fragment j of B's half image nh at wc * 4 + 2 j (+ 1).
   const int tq = frow >> 2, tp = frow & 3;
   const int t_row = 4 * fq + tq, t_sw = (t_row & 7) << 1;
   int ta_off[4], tb_off[2];
@@ -184,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
 
 #ifdef TRIBE_ABL_NO_LDSREAD   // ablation build: fragments stay what the prologue put in the registers (opaque to the optimiser)
 #define TRIBE_LDS_A(base, MH) _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[i][0]), "+v"(fa[i][1])); }
-#define TRIBE_LDS_B(base, NH, FB) _Pragma("unroll") for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(FB[j][0]), "+v"(FB[j][1])); }
+#define TRIBE_LDS_B(base) _Pragma("unroll") for (int j = 0; j < NB; ++j) { asm volatile("" : "+v"(fb[j][0]), "+v"(fb[j][1])); }
 #else
 #define TRIBE_LDS_A(base, MH)                                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
@@ -196,107 +220,120 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
       fa[i][1] = *(const bf16x8_t*)((base) + a_rd + (MH) * 8192 + i * 2048 + coff1);           \
     }                                                                                          \
   }
-#define TRIBE_LDS_B(base, NH, FB)                                                              \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+#define TRIBE_LDS_B(base)                                                                      \
+  _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                             \
     if (TN) {                                                                                  \
-      FB[j][0] = tr_frag((base) + (NH) * 16384 + tb_off[j]);                                   \
-      FB[j][1] = tr_frag((base) + (NH) * 16384 + tb_off[j] + 32 * 256);                        \
+      fb[j][0] = tr_frag((base) + (j >> 1) * 16384 + tb_off[j & 1]);                           \
+      fb[j][1] = tr_frag((base) + (j >> 1) * 16384 + tb_off[j & 1] + 32 * 256);                \
     } else {                                                                                   \
-      FB[j][0] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff0);           \
-      FB[j][1] = *(const bf16x8_t*)((base) + b_rd + (NH) * 4096 + j * 2048 + coff1);           \
+      fb[j][0] = *(const bf16x8_t*)((base) + b_rd + j * 2048 + coff0);                         \
+      fb[j][1] = *(const bf16x8_t*)((base) + b_rd + j * 2048 + coff1);                         \
     }                                                                                          \
   }
 #endif
 #ifdef TRIBE_ABL_NO_MFMA   // ablation build: the fragments are consumed by an empty asm instead of the matrix pipe
-#define TRIBE_MMA(MH, NH, FB)                                                                  \
+#define TRIBE_MMA(MH)                                                                          \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(fa[i][0]), "v"(fa[i][1])); } \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(FB[j][0]), "v"(FB[j][1])); }
+  _Pragma("unroll") for (int j = 0; j < NB; ++j) { asm volatile("" :: "v"(fb[j][0]), "v"(fb[j][1])); }
 #else
-#define TRIBE_MMA(MH, NH, FB)                                                                  \
+#define TRIBE_MMA(MH)                                                                          \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-    acc[(MH) * 4 + i][(NH) * 2 + j] =                                                          \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], FB[j][0], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
-    acc[(MH) * 4 + i][(NH) * 2 + j] =                                                          \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], FB[j][1], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+  _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                             \
+    acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[j][0], acc[(MH) * 4 + i][j], 0, 0, 0); \
+    acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[j][1], acc[(MH) * 4 + i][j], 0, 0, 0); \
   }
+#endif
+// Priority: ONE s_setprio 1 for the younger wave group (wr = 1, the arbitration loser on every slot) before the K loop instead of
+// flips around every MFMA cluster (guide T5, static form); the clusters are pinned between their barriers by sched_barrier.  Same-box
+// A/B (profiles/r03_b / r03_c_gemm_ablation.txt): FF1 +0.7 ... +5 %, FF2 +0.9 ... +3.6 % across two boxes, 8192^3 +-0.3 %.
+#ifdef TRIBE_GEMM_PRIO_FLIPS
+#define TRIBE_PRIO_UP() __builtin_amdgcn_s_setprio(1)
+#define TRIBE_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define TRIBE_PRIO_UP() __builtin_amdgcn_sched_barrier(0)
+#define TRIBE_PRIO_DOWN() __builtin_amdgcn_sched_barrier(0)
 #endif
 // The fragment reads are retired BEFORE the barrier: the two wave groups (wr = 0 / 1 = the two waves of every
 // SIMD) run one barrier apart, so while one group sits in this wait the other group's MFMA cluster owns the
 // matrix pipe, and at every barrier all LDS reads issued so far are complete (restaging is then hazard-free).
-#define TRIBE_PHASE_SYNC_MMA(MH, NH, FB)        \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-  __builtin_amdgcn_sched_barrier(0);            \
-  __builtin_amdgcn_s_barrier();                 \
-  __builtin_amdgcn_s_setprio(1);                \
-  TRIBE_MMA(MH, NH, FB)                         \
-  __builtin_amdgcn_s_setprio(0);                \
-  __builtin_amdgcn_s_barrier();
-
-#define TRIBE_PHASE_SYNC_MMA2(MH0, NH0, FB0, MH1, NH1, FB1) \
+#define TRIBE_PHASE_SYNC_MMA(MH)                           \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
   __builtin_amdgcn_sched_barrier(0);                       \
   TRIBE_STAMP(ts2);                                        \
   __builtin_amdgcn_s_barrier();                            \
   TRIBE_STAMP(ts3);                                        \
-  __builtin_amdgcn_s_setprio(1);                           \
-  TRIBE_MMA(MH0, NH0, FB0)                                 \
-  TRIBE_MMA(MH1, NH1, FB1)                                 \
-  __builtin_amdgcn_s_setprio(0);                           \
+  TRIBE_PRIO_UP();                                         \
+  TRIBE_MMA(MH)                                            \
+  TRIBE_PRIO_DOWN();                                       \
   TRIBE_STAMP(ts4);                                        \
   __builtin_amdgcn_s_barrier();                            \
   TRIBE_STAMP(ts5);                                        \
   TRIBE_STAMP_ACC(1, ts1, ts2); TRIBE_STAMP_ACC(2, ts2, ts3); TRIBE_STAMP_ACC(3, ts3, ts4); TRIBE_STAMP_ACC(4, ts4, ts5);
 
   const int nk = (int)(g.K / BK);
+  // K rotation: the workgroups that share an operand panel in an XCD's L2 (the 4 x 8 patch of tile_coords) walk K from different
+  // starting K-tiles, one apart, and wrap around.  Walking in lockstep, all sharers of a line wait on the SAME fill from beyond L2;
+  // one K-tile apart, the first brings the line in and the others hit (profiles/r03_b_gemm_ablation.txt: with every load an L2 hit
+  // FF1 / FF2 run 5 - 12 / 9 - 17 % faster).  Changes only the order of the f32 accumulation.
+  // Measured (profiles/r03_c_gemm_ablation.txt, same box, interleaved): FF1 +2.0 %, FF2 +1.3 %, 8192^3 +0.1 %.
+#ifdef TRIBE_GEMM_NO_KROT
+  const int krot = 0;
+#else
+  const int krot = ((tn & 7) + (tm & 3)) % nk;
+#endif
+  auto ktile = [&](int t) { const int k = t + krot; return k >= nk ? k - nk : k; };
 #ifdef TRIBE_GEMM_STAMPS
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
   unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0};  // 0 LDS reads, 1 stage + vmcnt wait, 2 barrier 1, 3 MFMA cluster, 4 barrier 2
 #endif
 
   // ---- prologue: K-tile 0 completely, K-tile 1 minus its last half-tile ----
-  stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
+  stage(0, 0, ktile(0)); stage(1, 0, ktile(0)); stage(3, 0, ktile(0));
   if (nk > 1) {
-    stage(0, 1, 1); stage(1, 1, 1); stage(2, 1, 1);
-    TRIBE_WAIT_VMCNT(6);
+    stage(0, 1, ktile(1)); stage(1, 1, ktile(1));
+    wait_vmcnt<2 + NB>();
   } else {
-    TRIBE_WAIT_VMCNT(0);
+    wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
   // stagger: group wr = 1 runs one barrier behind group wr = 0 for the whole K loop (LDS-read slots of one
   // group overlap MFMA slots of the other); group 0 pays the matching barrier after the loop.
   if (wr == 1) __builtin_amdgcn_s_barrier();
+#if !defined(TRIBE_GEMM_PRIO_FLIPS) && !defined(TRIBE_ABL_NO_PRIO)
+  if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     const char* base = smem + cur * BUF_BYTES;
-    // ---- phase A: quadrants (0,0) and (0,1): 16 fragment reads, 32 MFMAs.  Restage: the last half-tile (A half 1)
-    // of K-tile t+1 into the other buffer (its previous content was last read in phase B of K-tile t-1).
+    // ---- phase A: accumulator rows 0..3 x all NB columns: 2 NB + 8 fragment reads, 8 NB MFMAs.  Restage: the last half-tile
+    // (A half 1) of K-tile t+1 into the other buffer (its previous content was last read in phase B of K-tile t-1).
     TRIBE_STAMP(ts0);
-    TRIBE_LDS_B(base, 0, fb0)
-    TRIBE_LDS_B(base, 1, fb1)
+    TRIBE_LDS_B(base)
     TRIBE_LDS_A(base, 0)
     TRIBE_STAMP(ts1);
     TRIBE_STAMP_ACC(0, ts0, ts1);
-    // retire A half 1 of THIS K-tile (read in phase B): behind it in the queue are the three half-tiles of
-    // K-tile t+1 issued in the previous phase B and the one issued just now
-    if (t + 1 < nk) { stage(3, cur ^ 1, t + 1); TRIBE_WAIT_VMCNT(TRIBE_GEMM_VM_STEADY); } else { TRIBE_WAIT_VMCNT(0); }
-    TRIBE_PHASE_SYNC_MMA2(0, 0, fb0, 0, 1, fb1)
-    // ---- phase B: quadrants (1,1) and (1,0): 8 fragment reads, 32 MFMAs.  A half 0 and both B halves of THIS
-    // buffer were last read in phase A -> restage them for K-tile t+2.
+    // retire A half 1 of THIS K-tile (read in phase B): behind it in the queue are A half 0 + B of K-tile t+1 issued in the
+    // previous phase B (2 + NB loads) and the half-tile issued just now (2)
+    if (t + 1 < nk) { stage(3, cur ^ 1, ktile(t + 1)); wait_vmcnt<VM_STEADY>(); } else { wait_vmcnt<0>(); }
+    TRIBE_PHASE_SYNC_MMA(0)
+    // ---- phase B: accumulator rows 4..7: 8 fragment reads (the B fragments stay in registers), 8 NB MFMAs.  A half 0 and the
+    // B tile of THIS buffer were last read in phase A -> restage them for K-tile t+2.
     TRIBE_STAMP(ts0);
     TRIBE_LDS_A(base, 1)
     TRIBE_STAMP(ts1);
     TRIBE_STAMP_ACC(0, ts0, ts1);
     if (t + 2 < nk) {
-      stage(0, cur, t + 2); stage(1, cur, t + 2); stage(2, cur, t + 2);
-      TRIBE_WAIT_VMCNT(TRIBE_GEMM_VM_STEADY);  // retire A0/B0/B1 of K-tile t+1; behind them: A1(t+1) and the three just issued
+      const int k2 = ktile(t + 2);
+      stage(0, cur, k2); stage(1, cur, k2);
+      wait_vmcnt<VM_STEADY>();  // retire A0 / B of K-tile t+1; behind them: A1(t+1) (2) and the 2 + NB just issued
     } else if (t + 1 < nk) {
-      TRIBE_WAIT_VMCNT(2);  // behind them: only A1(t+1)
+      wait_vmcnt<2>();  // behind them: only A1(t+1)
     }
-    TRIBE_PHASE_SYNC_MMA2(1, 1, fb1, 1, 0, fb0)
+    TRIBE_PHASE_SYNC_MMA(1)
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_setprio(0);
 #ifdef TRIBE_GEMM_STAMPS
   if (g.gadd == nullptr && g.gadd_index != nullptr && lane == 0 && blockIdx.y == 0) {
     unsigned long long* dbg = (unsigned long long*)g.gadd_index + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -307,7 +344,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
 #undef TRIBE_LDS_B
 #undef TRIBE_MMA
 #undef TRIBE_PHASE_SYNC_MMA
-#undef TRIBE_PHASE_SYNC_MMA2
 
   // ---- epilogue straight from registers (quad transpose -> one 16-/8-byte store per lane).  Staging the sub-tile
   // through LDS to get whole-row 256-byte stores was measured 2x SLOWER (K = 64 probe: 158 vs 75 us f32, 138 vs 43 us
@@ -315,12 +351,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
   if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
     // nothing inside the sub-tile loop waits on memory (gemm_common.h); the staging buffers are idle by now
-    epilogue_fast<OUT_BF16, 8, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * 16384);
+    epilogue_fast<OUT_BF16, 8, NB, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 128, n0 + wc * WN, lane, smem + wave * (4 * NB * 1024));
     return;
   }
-  static_for<32>([&](auto t) {
-    constexpr int i = decltype(t)::value / 4, j = decltype(t)::value % 4;
-    epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * 64 + j * 16, lane);
+  static_for<8 * NB>([&](auto t) {
+    constexpr int i = decltype(t)::value / NB, j = decltype(t)::value % NB;
+    epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * WN + j * 16, lane);
   });
 }
 
@@ -420,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
   if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
     // (the K loop ends with a barrier: every wave's fragment reads are done, the buffers can stage the residual)
-    epilogue_fast<OUT_BF16, 4, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 64, n0 + wc * 64, lane, smem + wave * 16384);
+    epilogue_fast<OUT_BF16, 4, 4, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 64, n0 + wc * 64, lane, smem + wave * 16384);
     return;
   }
   static_for<16>([&](auto t) {
@@ -429,10 +465,199 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128x128x64(const tribe_gemm_de
   });
 }
 
+
+// =============================================================================================
+// 128 x 128 x 64 ring (round 3): small grids -- at most ~one workgroup per CU
+// =============================================================================================
+// The double-buffered 128^2 kernel above waits vmcnt(0) + barrier once per K-tile with one K-tile in flight.  That is fine with two
+// or three workgroups per CU covering for each other, and slow when the grid gives a CU ONE workgroup (BASELINE config at B = 4:
+// projector and voxel head are 256 tiles of 128^2 -- 0.18 / 0.16 of the MFMA peak in BENCH_r02): every K-step then pays a whole
+// L2 -> LDS round trip.  Here: 8 waves (two per SIMD; a wave owns 32 x 64), four 32-KiB stages = 128 KiB of LDS, THREE K-tiles in
+// flight by LDS-DMA across ONE raw barrier per K-tile with counted waits:
+//   iteration t:  s_waitcnt vmcnt(8)  (own loads of K-tile t landed; t+1, t+2 stay in flight)
+//                 s_barrier           (everybody's have; and everybody finished reading K-tile t-1: its reads were retired before
+//                                      the MFMAs of iteration t-1)
+//                 issue K-tile t+3 into the stage K-tile t-1 occupied
+//                 12 ds_read_b128, 16 MFMAs
+// Per K-step a CU moves 32 KiB from L2 for 512 MFMA cycles, so the stream (~0.5-0.6 us per 32 KiB per CU) bounds it, not the
+// matrix pipe; 96 KiB in flight keep that stream busy.
+namespace ring {
+constexpr int BM = 128, BN = 128, STAGES = 4;
+constexpr int TILE_BYTES = BM * BK * 2;           // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
+constexpr int SMEM_BYTES = STAGES * STAGE_BYTES;  // 128 KiB
+}  // namespace ring
+
+template <int OUT_BF16, int ROLE>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
+  using namespace ring;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+  const int wr = wave >> 1, wc = wave & 1;                    // 4 x 2 waves of 32 x 64
+
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int64_t z = blockIdx.y;
+  const int64_t b1 = z / g.batch0, b0 = z - b1 * g.batch0;
+  const int64_t b1g = g.gather1 ? g.gather1[b1] : b1;
+  const unsigned short* A = (const unsigned short*)g.A + (g.gather_a ? b1g : b1) * g.sA1 + b0 * g.sA0;
+  const unsigned short* B = (const unsigned short*)g.B + (g.gather_b ? b1g : b1) * g.sB1 + b0 * g.sB0;
+
+  // staging: a tile is 16 slabs of 8 rows x 128 bytes (row r at r * 128, 16-byte chunks XOR-swizzled by r & 7 on the SOURCE side);
+  // this wave moves slabs `wave` and `wave + 8` of both operands: 4 LDS-DMA loads per K-tile
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ srow;
+  const unsigned short* a_src[2];
+  const unsigned short* b_src[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = (wave + 8 * p) * 8 + srow;
+    int64_t gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;   // clamp: edge rows re-read a valid row, stores are masked
+    int64_t gc = n0 + r; gc = gc < g.N ? gc : g.N - 1;
+    a_src[p] = A + gr * g.lda + schunk * 8;
+    b_src[p] = B + gc * g.ldb + schunk * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE_BYTES + wave * 1024;
+    const int koff = kt * BK;
+    __builtin_amdgcn_global_load_lds((gptr_t)(a_src[0] + koff), (lptr_t)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(b_src[0] + koff), (lptr_t)(base + TILE_BYTES), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(a_src[1] + koff), (lptr_t)(base + 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(b_src[1] + koff), (lptr_t)(base + TILE_BYTES + 8192), 16, 0, 0);
+  };
+
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int coff0 = ((fq ^ (frow & 7)) << 4), coff1 = (((4 + fq) ^ (frow & 7)) << 4);
+  const int a_rd = (wr * 32 + frow) * 128;                 // + i * 2048 + coff
+  const int b_rd = TILE_BYTES + (wc * 64 + frow) * 128;    // + j * 2048 + coff
+
+  const int nk = (int)(g.K / BK);
+  if (0 < nk) stage(0, 0);
+  if (1 < nk) stage(1, 1);
+  if (2 < nk) stage(2, 2);
+  for (int t = 0; t < nk; ++t) {
+    const int ahead = nk - 1 - t;   // K-tiles issued behind K-tile t (capped at 2 by the ring)
+    if (ahead >= 2) wait_vmcnt<8>(); else if (ahead == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < nk) stage((t + 3) & 3, t + 3);
+    const char* base = smem + (t & 3) * STAGE_BYTES;
+    bf16x8_t fa[2][2], fb[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fb[j][0] = *(const bf16x8_t*)(base + b_rd + j * 2048 + coff0);
+      fb[j][1] = *(const bf16x8_t*)(base + b_rd + j * 2048 + coff1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[i][0] = *(const bf16x8_t*)(base + a_rd + i * 2048 + coff0);
+      fa[i][1] = *(const bf16x8_t*)(base + a_rd + i * 2048 + coff1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read retired before the next barrier can be reached (restaging is then safe)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+      }
+  }
+  __builtin_amdgcn_s_barrier();   // the staging buffers become the epilogue's scratch: every wave is past its last fragment read
+
+  const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
+  if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
+    epilogue_fast<OUT_BF16, 2, 4, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 32, n0 + wc * 64, lane, smem + wave * 8192);
+    return;
+  }
+  static_for<8>([&](auto t) {
+    constexpr int i = decltype(t)::value / 4, j = decltype(t)::value % 4;
+    epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc[i][j], m0 + wr * 32 + i * 16, n0 + wc * 64 + j * 16, lane);
+  });
+}
+
 }  // namespace
 
 
 
+
+// ---------------------------------------------------------------------------------------------
+// Launch tables.  gemm.hip is compiled in three parts (Makefile: -DTRIBE_GEMM_PART=0 / 1 / 2 -> gemm.o, gemm_p1.o, gemm_p2.o) so that
+// the instantiations build side by side: part 0 = the C entry points + the 256 x 256 kernel (and its transposed-operand form),
+// part 1 = the 256 x 192 kernel, part 2 = the two 128 x 128 kernels.  A build without the macro compiles everything in one unit.
+// ROLE only gives each call site of the path its own kernel symbol, so that rocprofv3 --stats reports per-operator rows.
+// ---------------------------------------------------------------------------------------------
+#ifndef TRIBE_GEMM_PART
+#define TRIBE_GEMM_PART -1
+#endif
+#define TRIBE_GEMM_HAS_PART(p) (TRIBE_GEMM_PART < 0 || TRIBE_GEMM_PART == (p))
+
+namespace tribe_gemm_detail {
+enum { KIND_SMALL = 0, KIND_BIG = 1, KIND_RING = 2 };
+// (output dtype, role symbol) pairs that exist as kernels; every other combination runs under the GENERIC symbol
+#define TRIBE_GEMM_PAIRS(X)                                                                                            \
+  X(0, 1, TRIBE_ROLE_GENERIC) X(1, 0, TRIBE_ROLE_GENERIC) X(2, 1, TRIBE_ROLE_EXT) X(3, 0, TRIBE_ROLE_EXT)              \
+  X(4, 0, TRIBE_ROLE_PROJECTOR) X(5, 1, TRIBE_ROLE_QKV) X(6, 0, TRIBE_ROLE_ATTN_SCORES) X(7, 1, TRIBE_ROLE_ATTN_PV)    \
+  X(8, 0, TRIBE_ROLE_OUT_PROJ) X(9, 1, TRIBE_ROLE_FF1) X(10, 0, TRIBE_ROLE_FF2) X(11, 0, TRIBE_ROLE_VOXEL_HEAD)
+void launch_big4(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+void launch_big3(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+void launch_ring(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+void launch_small(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+
+// the dynamic-LDS attribute is set once per kernel AND device (one process may drive several GPUs)
+template <auto KERNEL, int THREADS, int SMEM>
+static void launch_k(dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS, 1, 1), SMEM, s, *d, tiles_m, tiles_n);
+}
+#define TRIBE_GEMM_TABLE(NAME)                                                                                         \
+  void NAME(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n) {                  \
+    switch (pair) {                                                                                                    \
+      TRIBE_GEMM_PAIRS(TRIBE_GEMM_CASE_##NAME)                                                                         \
+      default: break;                                                                                                  \
+    }                                                                                                                  \
+  }
+#if TRIBE_GEMM_HAS_PART(0)
+#define TRIBE_GEMM_CASE_launch_big4(idx, bf, role) \
+  case idx: launch_k<gemm_nt_256x256x64<bf, role, 0, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+TRIBE_GEMM_TABLE(launch_big4)
+void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n) {
+  if (bf) launch_k<gemm_nt_256x256x64<1, TRIBE_ROLE_GENERIC, 1, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n);
+  else launch_k<gemm_nt_256x256x64<0, TRIBE_ROLE_GENERIC, 1, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n);
+}
+#endif
+#if TRIBE_GEMM_HAS_PART(1)
+#define TRIBE_GEMM_CASE_launch_big3(idx, bf, role) \
+  case idx: launch_k<gemm_nt_256x256x64<bf, role, 0, 3>, 512, 2 * (big::A_BYTES + 192 * BK * 2)>(grid, s, d, tiles_m, tiles_n); break;
+TRIBE_GEMM_TABLE(launch_big3)
+#endif
+#if TRIBE_GEMM_HAS_PART(2)
+#define TRIBE_GEMM_CASE_launch_ring(idx, bf, role) \
+  case idx: launch_k<gemm_nt_ring128<bf, role>, 512, ring::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+TRIBE_GEMM_TABLE(launch_ring)
+#define TRIBE_GEMM_CASE_launch_small(idx, bf, role) \
+  case idx: launch_k<gemm_nt_128x128x64<bf, role>, 256, small::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+TRIBE_GEMM_TABLE(launch_small)
+#endif
+}  // namespace tribe_gemm_detail
+
+#if TRIBE_GEMM_HAS_PART(0)
 // ---------------------------------------------------------------------------------------------
 // Optional in-library profile: HIP events recorded on the launch stream around every GEMM launch
 // while enabled (bench.py brackets its timed region with tribe_prof_begin / tribe_prof_end).
@@ -517,6 +742,49 @@ extern "C" int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64
   return 0;
 }
 
+
+namespace tribe_gemm_detail {
+// Which kernel and tile a launch gets.  sumsq_cols = columns per row_sumsq slot (one slot per wave column group).
+struct GemmPlan { int kind, bm, bn, sumsq_cols; };
+static GemmPlan gemm_plan(const tribe_gemm_desc* d) {
+  const int64_t nz = d->batch1 * d->batch0;
+  auto tiles = [&](int64_t bm, int64_t bn) { return ((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * nz; };
+  const int64_t t256 = tiles(256, 256), t128 = tiles(128, 128);
+  const bool fused_norm = d->c_bf16 || d->row_sumsq || d->row_scale;
+  // 256^2 tiles when both extents fill them and the grid still covers the chip, else 128^2
+  int use_big = (d->M >= 256 && d->N >= 256 && t256 >= 96);
+  // Narrow, short-K products whose 256^2 grid is under two rounds of the 256 CUs (ViT-g attention projection: 8192 x 1408 x 1408 =
+  // 192 tiles) run faster on 128^2 tiles (60 -> 47 us; profiles/r02_o_gemm_shapes.txt); with K > 2048 or N > 2048 the 256^2 tiles'
+  // higher operand reuse wins back more than the idle CUs cost.
+  if (use_big && t256 < 512 && t128 >= 512 && d->K <= 2048 && d->N <= 2048) use_big = 0;
+  // 256-wide tiles that hang a quarter or more over the edge of a narrow C (dQ = dS K per head: N = 384 fills 1.5 of them) lose more MFMA
+  // work than 128^2 tiles cost: batched 1024 x 384 x 1024, 128 batches: 246 -> 204 us
+  if (use_big && t128 >= 512 && (double)t128 * 128 * 128 * 1.25 <= (double)t256 * 256 * 256) use_big = 0;
+  if (fused_norm && d->N % 128 != 0) use_big = 1;   // (the launcher then reports the N it needs)
+  if (d->tile_hint == 1 || d->tile_hint == 3) use_big = 0;
+  if (d->tile_hint == 2 || d->tile_hint == 4) use_big = 1;
+  if (d->trans_ab) return {KIND_BIG, 256, 256, 64};
+  if (!use_big) {
+    // one workgroup per CU or fewer: the ring kernel (three K-tiles in flight); more: the double-buffered kernel, whose two or three
+    // co-resident workgroups per CU cover for each other
+    const bool ring = d->tile_hint == 3 || (d->tile_hint != 1 && t128 <= 256 && d->K >= 256);
+    return {ring ? KIND_RING : KIND_SMALL, 128, 128, 64};
+  }
+  // Tile quantisation on 256 CUs: a grid of 256 x 192 tiles when that cuts the rounds' worth of work (BASELINE config at B = 4, M = 4096:
+  // QKV 576 -> 768 tiles = 3 rounds of 3/4-size tiles instead of 3 of full size; out-proj / FF2 192 -> 256 tiles: the whole chip
+  // instead of 3/4 of it).  A 192-wide tile costs ~0.78 of a 256-wide one; large grids keep 256^2 (higher operand reuse).
+  int bn = 256;
+  if (d->tile_hint == 4) bn = 192;
+  else if (d->tile_hint == 0 && d->N % 192 == 0 && t256 <= 2048) {
+    const int64_t t192 = tiles(256, 192);
+    const double cost4 = (double)((t256 + 255) / 256), cost3 = (double)((t192 + 255) / 256) * 0.78;
+    if (cost3 < 0.95 * cost4) bn = 192;
+  }
+  if (fused_norm && d->N % bn != 0) bn = (d->N % 256 == 0) ? 256 : 192;
+  return {KIND_BIG, 256, bn, bn / 4};
+}
+}  // namespace tribe_gemm_detail
+
 extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(d != nullptr, "tribe_gemm_bf16: null descriptor");
   TRIBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "tribe_gemm_bf16: M, N, K must be positive (got %lld %lld %lld)",
@@ -542,37 +810,29 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   const int64_t nz = d->batch1 * d->batch0;
   if (d->c_bf16 || d->row_sumsq || d->row_scale) {
     // fused ScaleNorm operands exist only in the wait-free epilogue: insist on everything that path needs
-    TRIBE_REQUIRE(nz == 1 && d->N % 256 == 0 && !d->rowadd && !d->gadd && !d->aux && (d->act == TRIBE_ACT_NONE || d->act == TRIBE_ACT_GELU),
-                  "tribe_gemm_bf16: c_bf16 / row_sumsq / row_scale need an un-batched launch with N %% 256 == 0 and plain operators");
+    TRIBE_REQUIRE(nz == 1 && !d->rowadd && !d->gadd && !d->aux && (d->act == TRIBE_ACT_NONE || d->act == TRIBE_ACT_GELU),
+                  "tribe_gemm_bf16: c_bf16 / row_sumsq / row_scale need an un-batched launch with plain operators");
     TRIBE_REQUIRE(d->ldc % 4 == 0 && ((uintptr_t)d->C % 16) == 0 && (!d->bias || ((uintptr_t)d->bias % 16) == 0) &&
                       (!d->res || (d->ldres % 4 == 0 && ((uintptr_t)d->res % 16) == 0)) && (!d->res_scale || ((uintptr_t)d->res_scale % 16) == 0),
                   "tribe_gemm_bf16: c_bf16 / row_sumsq / row_scale need 16-byte aligned operands");
     TRIBE_REQUIRE((!d->c_bf16 && !d->row_sumsq) || d->c_dtype == TRIBE_F32, "tribe_gemm_bf16: c_bf16 / row_sumsq accompany an f32 C");
     TRIBE_REQUIRE(!d->c_bf16 || (d->ld_c_bf16 >= d->N && d->ld_c_bf16 % 4 == 0 && ((uintptr_t)d->c_bf16 % 8) == 0), "tribe_gemm_bf16: bad c_bf16");
-    TRIBE_REQUIRE(!d->row_sumsq || d->ld_row_sumsq >= d->N / 64, "tribe_gemm_bf16: ld_row_sumsq must cover N / 64 slots");
   }
-  // tile selection: 256^2 tiles when both extents fill them and the grid still covers the chip, else 128^2
-  const int64_t t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256) * nz, t128 = ((d->M + 127) / 128) * ((d->N + 127) / 128) * nz;
-  int use_big = (d->M >= 256 && d->N >= 256 && t256 >= 96);
-  // Narrow, short-K products whose 256^2 grid is under two rounds of the 256 CUs (ViT-g attention projection: 8192 x 1408 x 1408 =
-  // 192 tiles) run faster on 128^2 tiles (60 -> 47 us; profiles/r02_o_gemm_shapes.txt); with K > 2048 or N > 2048 the 256^2 tiles'
-  // higher operand reuse wins back more than the idle CUs cost.
-  if (use_big && t256 < 512 && t128 >= 512 && d->K <= 2048 && d->N <= 2048) use_big = 0;
-  // 256-wide tiles that hang a quarter or more over the edge of a narrow C (dQ = dS K per head: N = 384 fills 1.5 of them) lose more MFMA
-  // work than 128^2 tiles cost: batched 1024 x 384 x 1024, 128 batches: 246 -> 204 us
-  if (use_big && t128 >= 512 && (double)t128 * 128 * 128 * 1.25 <= (double)t256 * 256 * 256) use_big = 0;
-  if (d->tile_hint == 1) use_big = 0;
-  if (d->tile_hint == 2) use_big = 1;
+  const tribe_gemm_detail::GemmPlan plan = tribe_gemm_detail::gemm_plan(d);
+  if (d->c_bf16 || d->row_sumsq || d->row_scale) {
+    TRIBE_REQUIRE(d->N % plan.bn == 0, "tribe_gemm_bf16: c_bf16 / row_sumsq / row_scale need N (%lld) to be a multiple of the tile width %d",
+                  (long long)d->N, plan.bn);
+    TRIBE_REQUIRE(!d->row_sumsq || d->ld_row_sumsq >= d->N / plan.sumsq_cols, "tribe_gemm_bf16: ld_row_sumsq must cover N / %d slots (tribe_gemm_sumsq_slots)",
+                  plan.sumsq_cols);
+  }
   if (d->trans_ab) {
     TRIBE_REQUIRE(d->M >= 8 && d->N >= 8 && d->M % 8 == 0 && d->N % 8 == 0 && d->lda >= d->M && d->ldb >= d->N,
                   "tribe_gemm_bf16: trans_ab takes At [K, M] and Bt [K, N] with M and N multiples of 8 and lda >= M, ldb >= N");
     TRIBE_REQUIRE(!d->aux && d->act != TRIBE_ACT_SWIGLU && d->act != TRIBE_ACT_GLU && d->act != TRIBE_ACT_SILU && d->act != TRIBE_ACT_GELU_BWD &&
                       !d->gather_a && !d->gather_b,
                   "tribe_gemm_bf16: trans_ab supports the plain epilogue operators and no operand gather");
-    use_big = 1;
   }
-  const int64_t bm = use_big ? big::BM : small::BM, bn = use_big ? big::BN : small::BN;
-  const int64_t tiles_m = (d->M + bm - 1) / bm, tiles_n = (d->N + bn - 1) / bn;
+  const int64_t tiles_m = (d->M + plan.bm - 1) / plan.bm, tiles_n = (d->N + plan.bn - 1) / plan.bn;
   TRIBE_REQUIRE(tiles_m * tiles_n < (1ll << 31) && nz < 65536, "tribe_gemm_bf16: grid too large");
 
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nz, 1);
@@ -580,55 +840,44 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   const int role = (d->role >= 0 && d->role < TRIBE_ROLE_COUNT) ? d->role : TRIBE_ROLE_GENERIC;
   const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K * (double)nz;
   const int slot = prof_before(role, flops, s);
-#define TRIBE_GEMM_LAUNCH_K(KERNEL, THREADS, SMEM, BF, ROLE)                                                 \
-  do {                                                                                                       \
-    static bool attr_done = false;                                                                           \
-    if (!attr_done) {                                                                                        \
-      (void)hipFuncSetAttribute((const void*)KERNEL<BF, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
-      attr_done = true;                                                                                      \
-    }                                                                                                        \
-    hipLaunchKernelGGL((KERNEL<BF, ROLE>), grid, dim3(THREADS, 1, 1), SMEM, s, *d, (int)tiles_m, (int)tiles_n); \
-  } while (0)
-#define TRIBE_GEMM_LAUNCH(BF, ROLE)                                                                          \
-  do {                                                                                                       \
-    if (use_big) TRIBE_GEMM_LAUNCH_K(gemm_nt_256x256x64, 512, big::SMEM_BYTES, BF, ROLE);                    \
-    else TRIBE_GEMM_LAUNCH_K(gemm_nt_128x128x64, 256, small::SMEM_BYTES, BF, ROLE);                          \
-  } while (0)
+  const bool bf = d->c_dtype == TRIBE_BF16;
   if (d->trans_ab) {   // transposed operands: the 256^2 kernel only, plain epilogue operators
-    static bool tn_attr_done = false;
-    if (!tn_attr_done) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256x256x64<0, TRIBE_ROLE_GENERIC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM_BYTES);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256x256x64<1, TRIBE_ROLE_GENERIC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big::SMEM_BYTES);
-      tn_attr_done = true;
-    }
-    if (d->c_dtype == TRIBE_BF16)
-      hipLaunchKernelGGL((gemm_nt_256x256x64<1, TRIBE_ROLE_GENERIC, 1>), grid, dim3(512, 1, 1), big::SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
-    else
-      hipLaunchKernelGGL((gemm_nt_256x256x64<0, TRIBE_ROLE_GENERIC, 1>), grid, dim3(512, 1, 1), big::SMEM_BYTES, s, *d, (int)tiles_m, (int)tiles_n);
+    tribe_gemm_detail::launch_big4_tn(bf ? 1 : 0, grid, s, d, (int)tiles_m, (int)tiles_n);
     prof_after(slot, s);
     TRIBE_LAUNCH_CHECK();
     return 0;
   }
-  const bool bf = d->c_dtype == TRIBE_BF16;
   const bool ext = d->aux != nullptr || d->act == TRIBE_ACT_SWIGLU || d->act == TRIBE_ACT_GLU || d->act == TRIBE_ACT_SILU ||
                    d->act == TRIBE_ACT_GELU_BWD;
+  int pair = bf ? 0 : 1;   // GENERIC
   if (ext) {
-    if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_EXT); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_EXT);
-  } else
-  switch (role) {
-    case TRIBE_ROLE_PROJECTOR: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_PROJECTOR); break;
-    case TRIBE_ROLE_QKV: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_QKV); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
-    case TRIBE_ROLE_ATTN_SCORES: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_ATTN_SCORES); break;
-    case TRIBE_ROLE_ATTN_PV: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_ATTN_PV); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
-    case TRIBE_ROLE_OUT_PROJ: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_OUT_PROJ); break;
-    case TRIBE_ROLE_FF1: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_FF1); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
-    case TRIBE_ROLE_FF2: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_FF2); break;
-    case TRIBE_ROLE_VOXEL_HEAD: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_VOXEL_HEAD); break;
-    default: if (bf) TRIBE_GEMM_LAUNCH(1, TRIBE_ROLE_GENERIC); else TRIBE_GEMM_LAUNCH(0, TRIBE_ROLE_GENERIC); break;
+    pair = bf ? 2 : 3;
+  } else {
+    switch (role) {     // the (dtype, role) combinations the encode path launches have kernels of their own
+    case TRIBE_ROLE_PROJECTOR: if (!bf) pair = 4; break;
+    case TRIBE_ROLE_QKV: if (bf) pair = 5; break;
+    case TRIBE_ROLE_ATTN_SCORES: if (!bf) pair = 6; break;
+    case TRIBE_ROLE_ATTN_PV: if (bf) pair = 7; break;
+    case TRIBE_ROLE_OUT_PROJ: if (!bf) pair = 8; break;
+    case TRIBE_ROLE_FF1: if (bf) pair = 9; break;
+    case TRIBE_ROLE_FF2: if (!bf) pair = 10; break;
+    case TRIBE_ROLE_VOXEL_HEAD: if (!bf) pair = 11; break;
+    default: break;
+    }
   }
-#undef TRIBE_GEMM_LAUNCH
-#undef TRIBE_GEMM_LAUNCH_K
+  using namespace tribe_gemm_detail;
+  if (plan.kind == KIND_BIG && plan.bn == 192) launch_big3(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
+  else if (plan.kind == KIND_BIG) launch_big4(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
+  else if (plan.kind == KIND_RING) launch_ring(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
+  else launch_small(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
   prof_after(slot, s);
   TRIBE_LAUNCH_CHECK();
   return 0;
 }
+
+extern "C" int tribe_gemm_sumsq_slots(const tribe_gemm_desc* d) {
+  TRIBE_REQUIRE(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0 && d->batch1 > 0 && d->batch0 > 0, "tribe_gemm_sumsq_slots: bad descriptor");
+  const tribe_gemm_detail::GemmPlan plan = tribe_gemm_detail::gemm_plan(d);
+  return (int)(d->N / plan.sumsq_cols);
+}
+#endif  // part 0

@@ -301,65 +301,70 @@ __device__ __forceinline__ void static_for(F&& f) {
 // masked; in the EXT kernels also the training operators (pre-activation store, GELU' from the saved pre-activation).
 // The periodic row add (pos_embed) takes the residual's place when there is no residual; gathered adds, a row add together
 // with a residual, and tiles that cross N take the generic path.
-template <int OUT_BF16, int NI, int EXT>
-__device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t (&acc)[NI][4], int64_t mw, int64_t nw, int lane,
+// NI x NJ = the wave's accumulator grid of 16 x 16 sub-tiles; a round covers RI = min(NI, 4) sub-tile rows x NJ columns (<= 16 sub-tiles,
+// 1 KiB of LDS each for the tile-shaped addend).  Row sums of squares go to slot nw / (16 NJ): one slot per wave column group.
+template <int OUT_BF16, int NI, int NJ, int EXT>
+__device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t (&acc)[NI][NJ], int64_t mw, int64_t nw, int lane,
                                               char* lds_wave) {
+  constexpr int RI = NI >= 4 ? 4 : NI;
+  static_assert(NI % RI == 0 && NJ >= 1 && NJ <= 4, "accumulator grid");
   const int64_t row0 = mw + ((lane >> 4) << 2) + (lane & 3);      // + 16 i
   const int64_t col0 = nw + (((lane & 15) >> 2) << 2);            // + 16 j
   const bool bias_col = g.bias_mode == TRIBE_BIAS_COL, bias_row = g.bias_mode == TRIBE_BIAS_ROW;
   const bool res_scaled = c.res && g.res_scale;
   const bool pair_act = EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU);
-  float4 bcol[4], rsc[4];
-  static_for<4>([&](auto jt) {
+  float4 bcol[NJ], rsc[NJ];
+  static_for<NJ>([&](auto jt) {
     constexpr int j = decltype(jt)::value;
     if (bias_col) bcol[j] = *(const float4*)(c.bias + col0 + j * 16);
     if (res_scaled) rsc[j] = *(const float4*)(g.res_scale + col0 + j * 16);
   });
-  constexpr int ROUNDS = NI / 4;
+  constexpr int ROUNDS = NI / RI;
   static_for<ROUNDS>([&](auto rt) {
     constexpr int round = decltype(rt)::value;
-    float brow[4], srow[4], ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    float brow[RI], srow[RI], ssq[RI];
+    static_for<RI>([&](auto it) { ssq[decltype(it)::value] = 0.f; });
     if (bias_row) {
-      static_for<4>([&](auto it) {
-        const int64_t r = row0 + (round * 4 + decltype(it)::value) * 16;
+      static_for<RI>([&](auto it) {
+        const int64_t r = row0 + (round * RI + decltype(it)::value) * 16;
         brow[decltype(it)::value] = r < g.M ? c.bias[r] : 0.f;
       });
     }
     if (g.row_scale) {   // ScaleNorm of the A rows, applied to the product (see tribe_gemm_desc)
-      static_for<4>([&](auto it) {
-        const int64_t r = row0 + (round * 4 + decltype(it)::value) * 16;
+      static_for<RI>([&](auto it) {
+        const int64_t r = row0 + (round * RI + decltype(it)::value) * 16;
         srow[decltype(it)::value] = r < g.M ? g.row_scale[r] : 0.f;
       });
     }
     // the tile-shaped addend: the residual, or (when there is none) the periodic row add -- pos_embed[t] of the projector
     const bool tile_add = c.res || g.rowadd;
     if (tile_add) {
-      static_for<4>([&](auto it) {
-        constexpr int i4 = decltype(it)::value, i = round * 4 + i4;
+      static_for<RI>([&](auto it) {
+        constexpr int i4 = decltype(it)::value, i = round * RI + i4;
         const int64_t r = row0 + i * 16;
         if (r < g.M) {   // rows past M (bottom tile row): the lane neither fetches nor stores
           const float* src = c.res ? c.res + r * g.ldres + col0
                                    : g.rowadd + (int64_t)((unsigned)r % (unsigned)g.rowadd_period) * g.ld_rowadd + col0;
-          static_for<4>([&](auto jt) {
+          static_for<NJ>([&](auto jt) {
             constexpr int j = decltype(jt)::value;
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 16), (lptr_t)(lds_wave + (i4 * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 16), (lptr_t)(lds_wave + (i4 * NJ + j) * 1024), 16, 0, 0);
           });
         }
       });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA's LDS writes are invisible to the compiler's own counters
     }
     // training dgrad through GELU: the saved bf16 pre-activations of the round, fetched together (32 VGPRs, EXT kernels only)
-    u16x4_t pre[EXT ? 16 : 1];
+    u16x4_t pre[EXT ? RI * NJ : 1];
     const bool gelu_bwd = EXT && g.act == TRIBE_ACT_GELU_BWD;
     if (gelu_bwd) {
-      static_for<16>([&](auto st) {
-        constexpr int s = decltype(st)::value, i = round * 4 + s / 4, j = s % 4;
+      static_for<RI * NJ>([&](auto st) {
+        constexpr int s = decltype(st)::value, i = round * RI + s / NJ, j = s % NJ;
         const int64_t r = row0 + i * 16;
         pre[EXT ? s : 0] = r < g.M ? *(const u16x4_t*)((const unsigned short*)g.aux + c.c_off + r * g.ld_aux + col0 + j * 16) : u16x4_t{0, 0, 0, 0};
       });
     }
-    static_for<16>([&](auto st) {
-      constexpr int s = decltype(st)::value, i4 = s / 4, i = round * 4 + i4, j = s % 4;
+    static_for<RI * NJ>([&](auto st) {
+      constexpr int s = decltype(st)::value, i4 = s / NJ, i = round * RI + i4, j = s % NJ;
       const int64_t row = row0 + i * 16;
       float v[4];
       quad_transpose(acc[i][j], g.alpha, lane, v);   // all four lanes of a quad take part, including those whose row is past M
@@ -426,14 +431,14 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
       }
     });
     if (!OUT_BF16 && g.row_sumsq) {
-      // the 16 values a lane holds of row i (4 sub-tiles x 4 columns) + the three other lanes of that row -> one slot per wave
-      static_for<4>([&](auto it) {
+      // the 4 NJ values a lane holds of row i (NJ sub-tiles x 4 columns) + the three other lanes of that row -> one slot per wave
+      static_for<RI>([&](auto it) {
         constexpr int i4 = decltype(it)::value;
         float t = ssq[i4];
         t += __shfl_xor(t, 4, 64);
         t += __shfl_xor(t, 8, 64);
-        const int64_t r = row0 + (round * 4 + i4) * 16;
-        if ((lane & 12) == 0 && r < g.M) g.row_sumsq[r * g.ld_row_sumsq + (nw >> 6)] = t;
+        const int64_t r = row0 + (round * RI + i4) * 16;
+        if ((lane & 12) == 0 && r < g.M) g.row_sumsq[r * g.ld_row_sumsq + (int64_t)((unsigned)nw / (unsigned)(16 * NJ))] = t;
       });
     }
   });

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_nt_256x256x128(const tribe_ge
   // bf16 per 16384 x 3072 output): the extra LDS round trip costs more than the wider store segments save.
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
   if (epilogue_fast_ok<EXT>(g, ctx) && n0 + BN <= g.N) {
-    epilogue_fast<OUT_BF16, 8, EXT>(g, ctx, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * 16384);
+    epilogue_fast<OUT_BF16, 8, 4, EXT>(g, ctx, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * 16384);
     return;
   }
   static_for<32>([&](auto t) {

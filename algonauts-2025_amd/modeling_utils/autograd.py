@@ -202,14 +202,19 @@ class _FusedQKVPacks:
     def __init__(self) -> None:
         self._c: dict[int, list] = {}     # id(wq) -> [weakref, sig, fused, fusedT, [weak refs of the three weights]]
 
-    def _refreshed(self, key: int) -> None:
+    def _refreshed(self, key: int, index: int, version: int) -> None:
+        """HipAdam wrote the bf16 rows of weight `index` together with its f32 value, which now stands at `version`.  Only THAT
+        weight's signature entry moves: a sibling written outside the optimiser (load_state_dict, copy_) that got no gradient in this
+        step keeps its recorded version, still mismatches in get() and is repacked there."""
         hit = self._c.get(key)
         if hit is None:
             return
         ws = [r() for r in hit[4]]
         if any(w is None for w in ws) or hit[0]() is not ws[0]:
             return
-        hit[1] = tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in ws)   # current once all three were stepped; a partial update repacks
+        sig = list(hit[1])
+        sig[index] = (ws[index].data_ptr(), version, tuple(ws[index].shape))
+        hit[1] = tuple(sig)
         hit[3] = None                                                            # the transpose is re-derived on the next get()
 
     def get(self, ws: tuple[torch.Tensor, torch.Tensor, torch.Tensor]) -> tuple[torch.Tensor, torch.Tensor]:
@@ -233,7 +238,7 @@ class _FusedQKVPacks:
             self._c[key] = hit
             for i, w in enumerate(ws):
                 if isinstance(w, torch.nn.Parameter) and w.is_contiguous():
-                    shadow.register(w, fused[i * N:(i + 1) * N], lambda version, k=key: self._refreshed(k))
+                    shadow.register(w, fused[i * N:(i + 1) * N], lambda version, k=key, i=i: self._refreshed(k, i, version))
         if hit[3] is None:
             N3, K = hit[2].shape
             hit[3] = transpose_bf16(hit[2], 1, N3, K, 0, K)[0]

@@ -172,11 +172,23 @@ class EncoderDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 3
+# (struct name, mirror) in the order of tribe_abi_struct_sizes(): compared with the library's sizeof() at load time
+STRUCT_MIRRORS = [
+    ("tribe_gemm_desc", GemmDesc), ("tribe_attention_desc", AttentionDesc), ("tribe_encoder_layer", EncoderLayer), ("tribe_encoder_desc", EncoderDesc),
+    ("tribe_vit_layer", VitLayer), ("tribe_vit_fp8_layer", VitFp8Layer), ("tribe_vjepa2_desc", Vjepa2Desc), ("tribe_conformer_layer", ConformerLayer),
+    ("tribe_conformer_fp8_layer", ConformerFp8Layer), ("tribe_w2vbert_desc", W2vBertDesc), ("tribe_llama_layer", LlamaLayer),
+    ("tribe_llama_fp8_layer", LlamaFp8Layer), ("tribe_llama_desc", LlamaDesc), ("tribe_feature_piece", FEATURE_PIECE_DTYPE),
+    ("tribe_adam_tensor", ADAM_TENSOR_DTYPE),
+]
+
 # name -> (restype, argtypes); must cover every symbol include/tribe_hip.h declares
 SIGNATURES = {
     "tribe_version": (C.c_int, []),
+    "tribe_abi_struct_sizes": (C.c_int, [C.POINTER(i64), i32]),
     "tribe_last_error": (C.c_char_p, []),
     "tribe_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tribe_gemm_sumsq_slots": (C.c_int, [C.POINTER(GemmDesc)]),
     "tribe_prof_begin": (C.c_int, [i32]),
     "tribe_prof_end": (C.c_int, [i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "tribe_pack_weight_bf16": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),
@@ -269,8 +281,14 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the export is missing
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.tribe_version() != 1:
-            raise TribeHipError(f"ABI version mismatch: library reports {handle.tribe_version()}, binding expects 1")
+        if handle.tribe_version() != ABI_VERSION:
+            raise TribeHipError(f"ABI version mismatch: library reports {handle.tribe_version()}, binding expects {ABI_VERSION}")
+        got = (i64 * len(STRUCT_MIRRORS))()
+        n = handle.tribe_abi_struct_sizes(got, len(STRUCT_MIRRORS))
+        want = [m.itemsize if isinstance(m, _np.dtype) else C.sizeof(m) for _, m in STRUCT_MIRRORS]
+        if n != len(want) or list(got) != want:
+            bad = [f"{name}: library {g} / binding {w}" for (name, _), g, w in zip(STRUCT_MIRRORS, got, want) if g != w]
+            raise TribeHipError(f"descriptor layout mismatch between {path.name} and its ctypes mirrors ({n} structs): " + "; ".join(bad))
         _lib = handle
     return _lib
 

@@ -83,6 +83,7 @@ def launch_ranks(n: int, argv: list[str]) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRIBE_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env))
     rc = 0
+    deadline = None   # set at the first failure: survivors get SIGTERM, then 30 s, then SIGKILL (a rank stuck in a collective ignores SIGTERM)
     try:
         pending = set(range(n))
         while pending:
@@ -93,9 +94,13 @@ def launch_ranks(n: int, argv: list[str]) -> int:
                 pending.discard(r)
                 if code != 0 and rc == 0:
                     rc = code
+                    deadline = time.monotonic() + 30.0
                     print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
                     for q in pending:
                         procs[q].terminate()
+            if deadline is not None and pending and time.monotonic() > deadline:
+                print(f"bench.py: ranks {sorted(pending)} ignored SIGTERM for 30 s; killing them", file=sys.stderr, flush=True)
+                break   # the finally clause kills what is left; the recorded non-zero code is returned
             time.sleep(0.05)
     finally:
         for p in procs:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TRIBE_ABI_VERSION 1
+#define TRIBE_ABI_VERSION 3   /* bumped whenever a descriptor struct changes layout (round 2 changed three without a bump) */
 
 enum tribe_dtype { TRIBE_F32 = 0, TRIBE_BF16 = 1, TRIBE_F64 = 2 };
 enum tribe_act {
@@ -50,6 +50,11 @@ enum tribe_gemm_role {
 };
 
 int tribe_version(void);
+/* sizeof() of every descriptor struct of this header, in declaration order (gemm_desc, attention_desc, encoder_layer, encoder_desc,
+ * vit_layer, vit_fp8_layer, vjepa2_desc, conformer_layer, conformer_fp8_layer, w2vbert_desc, llama_layer, llama_fp8_layer, llama_desc,
+ * feature_piece, adam_tensor): a binding compares them with its own mirrors at load time, so that a stale library or a stale mirror
+ * fails loudly instead of mis-striding a table.  Writes min(n, 15) entries, returns 15. */
+int tribe_abi_struct_sizes(int64_t* sizes, int32_t n);
 /* thread-local, valid until the next failing call on this thread */
 const char* tribe_last_error(void);
 
@@ -83,14 +88,15 @@ typedef struct tribe_gemm_desc {
   void* aux; int64_t ld_aux;
   int32_t gather_b;        /* gather1 also replaces b1 for the B operand */
   int32_t role;            /* enum tribe_gemm_role */
-  int32_t tile_hint;       /* 0 = automatic, 1 = force 128x128 tiles, 2 = force 256x256 tiles (tests / tuning) */
+  int32_t tile_hint;       /* 0 = automatic; tests / tuning: 1 = 128x128 double-buffered, 2 = 256x256, 3 = 128x128 ring, 4 = 256x192 */
   /* 1 = the operands are given TRANSPOSED: A is At [K, M] (lda >= M), B is Bt [K, N] (ldb >= N), C[m][n] = sum_k At[k][m] Bt[k][n] --
    * the weight gradient dW = dY^T X straight from the row-major dY [tokens, N_out] and X [tokens, K_in] the forward produced, without
    * the explicit transposes (torch.nn.functional.linear's backward in the reference).  M, N multiples of 8; plain epilogue only. */
   int32_t trans_ab;
   /* ScaleNorm folded into the GEMMs either side of it (x_transformers pre-norm: y = W . (x * s_m), s_m = g sqrt(d) / |x_m|):
-   * the PRODUCER of x (f32 C) also emits a bf16 copy and per-row partial sums of squares, one slot per 64 output columns
-   * (row_sumsq[m * ld_row_sumsq + n / 64]); tribe_rownorm_scale_fwd turns them into s_m; the CONSUMER multiplies its
+   * the PRODUCER of x (f32 C) also emits a bf16 copy and per-row partial sums of squares, one slot per wave column group
+   * (row_sumsq[m * ld_row_sumsq + n / w], w = 64 or 48 columns by the tile the launch gets: tribe_gemm_sumsq_slots() says how
+   * many slots per row THIS descriptor will write -- pass it on as n_partial); tribe_rownorm_scale_fwd turns them into s_m; the CONSUMER multiplies its
    * accumulator rows by row_scale[m] before bias / activation (the scaling commutes with the product).  Un-batched
    * launches whose N is a multiple of the tile and whose operands are 16-byte aligned only; NULL = unused. */
   uint16_t* c_bf16; int64_t ld_c_bf16;
@@ -99,6 +105,9 @@ typedef struct tribe_gemm_desc {
 } tribe_gemm_desc;
 
 int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);
+/* number of row_sumsq slots per row the launch of `desc` writes (N / 64, or N / 48 when the launch gets 256 x 192 tiles); < 0 on a bad
+ * descriptor.  Depends on M, N, K, the batch counts, tile_hint and the fused-norm operands only. */
+int tribe_gemm_sumsq_slots(const tribe_gemm_desc* desc);
 /* scale[m] = g[0] * gain_scale / max(sqrt(sum_p partial[m, p]), eps): the ScaleNorm factor from the partial sums of squares a
  * GEMM epilogue left in row_sumsq (partial f32 [rows, n_partial], row-major). */
 int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partial, const float* g, float gain_scale, float eps,

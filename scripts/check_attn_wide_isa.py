@@ -3,7 +3,8 @@
   * no compiler-generated v_accvgpr_* or MFMA outside the ASMSTART / ASMEND blocks (a0..a191 hold O^T and belong to the asm
     statements of attn_acc_regs.h; the compiler must not allocate accumulator registers of its own),
   * prints the register budget and the instruction mix of the key loop.
-Usage: python scripts/check_attn_wide_isa.py [--no-gemm]"""
+Usage: python scripts/check_attn_wide_isa.py [--no-gemm | --attention-only]
+(--attention-only: attention.hip alone -- the Makefile runs this after compiling attention.o and fails the build on a violation.)"""
 import re
 import subprocess
 import sys
@@ -32,8 +33,9 @@ def device_isa(sources: list[str]) -> dict[str, str]:
         return isa
 
 
-WITH_GEMM = "--no-gemm" not in sys.argv[1:]   # gemm.hip takes two minutes to compile (its role instantiations); the unit test skips it
-ISA = device_isa(["attention.hip", "attention_d64.hip"] + (["gemm.hip"] if WITH_GEMM else []))
+ATTN_ONLY = "--attention-only" in sys.argv[1:]
+WITH_GEMM = "--no-gemm" not in sys.argv[1:] and not ATTN_ONLY   # gemm.hip takes two minutes to compile (its role instantiations); the unit test skips it
+ISA = device_isa(["attention.hip"] + ([] if ATTN_ONLY else ["attention_d64.hip"]) + (["gemm.hip"] if WITH_GEMM else []))
 text = ISA["attention.hip"]
 def audit(kernel: str, max_regs: int) -> bool:
     m = re.search(rf"^(_ZN\S*{kernel}\S*):.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
@@ -83,7 +85,8 @@ def no_scratch(source: str, kernels: list[str]) -> bool:
     return good
 
 
-ok &= no_scratch("attention_d64.hip", ["attn_fwd_d64_kernel", "attn_fwd_d64_pair_kernel"])
+if not ATTN_ONLY:
+    ok &= no_scratch("attention_d64.hip", ["attn_fwd_d64_kernel", "attn_fwd_d64_pair_kernel"])
 if WITH_GEMM:
     ok &= no_scratch("gemm.hip", ["gemm_nt_256x256x64"])
 if not ok:

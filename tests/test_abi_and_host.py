@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in include/tribe_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(declared)
-    assert handle.tribe_version() == 1
+    assert handle.tribe_version() == _lib.ABI_VERSION
 
 
 def test_ctypes_struct_layout_matches_c(tmp_path):

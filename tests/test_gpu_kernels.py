@@ -39,7 +39,7 @@ def test_gemm_identity_asymmetric(ops):
     torch.testing.assert_close(out.cpu(), b.t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("tile_hint", [1, 2])  # 1 = 128x128 tiles, 2 = 256x256 tiles (counted-vmcnt pipeline)
+@pytest.mark.parametrize("tile_hint", [1, 2, 3, 4])  # 1 = 128x128 double-buffered, 2 = 256x256 (counted-vmcnt pipeline), 3 = 128x128 ring, 4 = 256x192
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1000, 192), (1000, 298, 3072), (4, 5, 64), (129, 129, 64),
                                    (256, 256, 64), (512, 768, 320), (257, 511, 128), (1024, 1024, 384)])
 def test_gemm_shapes(ops, M, N, K, tile_hint):
@@ -60,9 +60,16 @@ def test_gemm_big_tiles_race_screen(ops):
     torch.testing.assert_close(first, ref, rtol=1e-5, atol=2e-3)  # different K-summation order only
     for _ in range(20):
         assert torch.equal(ops.gemm_nt(a, b, tile_hint=2), first)
+    # the round-3 kernels keep loads in flight across barriers as well: 256 x 192 tiles (4 + 3 loads) and the 128^2 ring (3 K-tiles)
+    for hint in (3, 4):
+        first = ops.gemm_nt(a, b, tile_hint=hint)
+        torch.testing.assert_close(first, ref, rtol=1e-5, atol=2e-3)
+        for _ in range(20):
+            assert torch.equal(ops.gemm_nt(a, b, tile_hint=hint), first)
 
 
-@pytest.mark.parametrize("M,N,hint", [(96, 160, 0), (96, 158, 0), (384, 320, 2), (70, 256, 1), (1001, 512, 2), (257, 256, 2), (1000, 1024, 0)])
+@pytest.mark.parametrize("M,N,hint", [(96, 160, 0), (96, 158, 0), (384, 320, 2), (70, 256, 1), (1001, 512, 2), (257, 256, 2), (1000, 1024, 0),
+                                      (70, 256, 3), (96, 158, 3), (200, 128, 3), (384, 384, 4), (257, 192, 4), (1001, 576, 4), (300, 200, 4)])
 def test_gemm_epilogues(ops, M, N, hint):
     """Every operator of the epilogue, on tiles that take the generic path (N not a multiple of the tile, row / gathered adds)
     and on tiles that take the wait-free interior path (N a multiple of the tile; M = 70 / 257 / 1001 end inside a quad of
@@ -108,13 +115,14 @@ def test_gemm_epilogues(ops, M, N, hint):
 
 def test_gemm_epilogue_fuzz(ops):
     """Random shapes x random operator sets x both tile sizes against an f64 reference: the wait-free interior epilogue, the
-    generic edge epilogue and the masked bottom rows must agree on every combination (48 seeded cases)."""
+    generic edge epilogue and the masked bottom rows must agree on every combination (96 seeded cases over the four tile kernels)."""
     rng = np.random.default_rng(2025)
-    for case in range(48):
-        hint = int(rng.integers(1, 3))
-        tile = 128 if hint == 1 else 256
+    for case in range(96):
+        hint = int(rng.integers(1, 3)) if case < 48 else int(rng.integers(3, 5))   # (the first 48 cases are round 2's, unchanged)
+        tile = 128 if hint in (1, 3) else 256
+        tile_n = {1: 128, 2: 256, 3: 128, 4: 192}[hint]
         M = int(rng.choice([int(rng.integers(1, 3 * tile)), tile, 2 * tile + 3]))
-        N = int(rng.choice([tile, 2 * tile, int(rng.integers(1, 2 * tile)) // 4 * 4 + 4]))
+        N = int(rng.choice([tile_n, 2 * tile_n, int(rng.integers(1, 2 * tile_n)) // 4 * 4 + 4]))
         K = 64 * int(rng.integers(1, 5))
         g = torch.Generator().manual_seed(case)
         a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / K**0.5)
@@ -153,6 +161,54 @@ def test_gemm_epilogue_fuzz(ops):
         tol = 2**-7 if out_bf16 else 1e-4
         err = (got - want).abs().max() / max(1.0, float(want.abs().max()))
         assert err < tol, (case, M, N, K, hint, use_bias, use_res, use_rs, use_gelu, use_rowadd, out_bf16, float(err))
+
+
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4])
+def test_gemm_fused_norm_operands(ops, hint):
+    """The ScaleNorm operands of the epilogue (c_bf16 copy, per-row partial sums of squares, row_scale on the consumer side) on every
+    tile kernel: the number of slots per row follows the tile (tribe_gemm_sumsq_slots), their sum is the row's sum of squares."""
+    import ctypes as C
+
+    from tribe_hip import _lib
+
+    M, N, K = 300, 768, 128
+    g = torch.Generator().manual_seed(11 + hint)
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / K**0.5)
+    res, rs, bias = torch.randn(M, N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    A, B, x = _dev(a).bfloat16(), _dev(b).bfloat16(), _dev(res.clone())
+    rsd, biasd = _dev(rs), _dev(bias)
+    xb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, 1, 1
+    d.A, d.lda, d.B, d.ldb = A.data_ptr(), K, B.data_ptr(), K
+    d.C, d.ldc, d.c_dtype, d.alpha, d.tile_hint = x.data_ptr(), N, _lib.F32, 1.0, hint
+    d.bias, d.bias_mode = biasd.data_ptr(), _lib.BIAS_COL
+    d.res, d.ldres, d.res_scale = x.data_ptr(), N, rsd.data_ptr()
+    d.c_bf16, d.ld_c_bf16 = xb.data_ptr(), N
+    ssq = torch.full((M, N // 32), float("nan"), device="cuda")
+    d.row_sumsq = ssq.data_ptr()
+    slots = _lib.lib().tribe_gemm_sumsq_slots(C.byref(d))
+    assert slots == {0: N // 64, 1: N // 64, 2: N // 64, 3: N // 64, 4: N // 48}[hint]
+    d.ld_row_sumsq = slots
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(d), s), "gemm")
+    want = a.double() @ b.double().t() + bias.double() + res.double() * rs.double()
+    torch.testing.assert_close(x.cpu().double(), want, rtol=1e-5, atol=1e-4)
+    assert torch.equal(xb.cpu(), x.cpu().bfloat16())
+    part = ssq.flatten()[: M * slots].view(M, slots).cpu().double()
+    torch.testing.assert_close(part.sum(1), (x.cpu().double() ** 2).sum(1), rtol=1e-5, atol=1e-4)
+    # consumer side: accumulator rows scaled before bias and activation
+    scale = torch.rand(M, generator=g) + 0.5
+    sd = _dev(scale)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    c = _lib.GemmDesc()
+    c.M, c.N, c.K, c.batch1, c.batch0 = M, N, K, 1, 1
+    c.A, c.lda, c.B, c.ldb = A.data_ptr(), K, B.data_ptr(), K
+    c.C, c.ldc, c.c_dtype, c.alpha, c.tile_hint = out.data_ptr(), N, _lib.BF16, 1.0, hint
+    c.bias, c.bias_mode, c.act, c.row_scale = biasd.data_ptr(), _lib.BIAS_COL, _lib.ACT_GELU, sd.data_ptr()
+    _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(c), s), "gemm")
+    want = torch.nn.functional.gelu((a.double() @ b.double().t()) * scale.double()[:, None] + bias.double())
+    torch.testing.assert_close(out.cpu().double(), want, rtol=2**-7, atol=2e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64])
