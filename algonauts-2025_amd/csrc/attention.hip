@@ -967,7 +967,16 @@ int tribe_internal_attention_fused_supported(int dim_head) {
 
 // the work behind tribe_attention_fwd_ex; q_cos / q_sin / q_rot_dim: partial rotary of Q applied by the kernel itself (nullptr: q arrives
 // rotated; only tribe_internal_attention_fused_qrot passes tables, and only where tribe_internal_attention_rotates_q holds)
+static int attention_dispatch_impl(const tribe_attention_desc* d, const float* q_cos, const float* q_sin, int q_rot_dim, void* stream);
 static int attention_dispatch(const tribe_attention_desc* d, const float* q_cos, const float* q_sin, int q_rot_dim, void* stream) {
+  // profile slot of the "attention" role (bench.py's by_kernel table): QK^T and PV, 4 * T * dim_head flop per query row and head
+  const double flops = d ? 4.0 * (double)d->T * (double)d->dim_head * (double)d->T * (double)d->heads_q * (double)d->B * (d->causal ? 0.5 : 1.0) : 0.0;
+  const int slot = tribe_internal_prof_before(TRIBE_ROLE_ATTENTION, flops, (hipStream_t)stream);
+  const int rc = attention_dispatch_impl(d, q_cos, q_sin, q_rot_dim, stream);
+  tribe_internal_prof_after(slot, (hipStream_t)stream);
+  return rc;
+}
+static int attention_dispatch_impl(const tribe_attention_desc* d, const float* q_cos, const float* q_sin, int q_rot_dim, void* stream) {
   TRIBE_REQUIRE(d && d->q && d->k && d->v && d->out, "tribe_attention_fwd_ex: null pointer");
   TRIBE_REQUIRE(d->B > 0 && d->T > 0 && d->heads_q > 0 && d->heads_kv > 0 && d->heads_q % d->heads_kv == 0,
                 "tribe_attention_fwd_ex: bad shape (B=%lld T=%lld heads %d/%d)", (long long)d->B, (long long)d->T, d->heads_q, d->heads_kv);

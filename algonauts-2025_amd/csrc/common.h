@@ -67,4 +67,9 @@ void tribe_set_error(const char* fmt, ...);
     }                                                                  \
   } while (0)
 
+// in-library HIP-event profile (gemm.hip; bench.py brackets its timed region with tribe_prof_begin / tribe_prof_end): other launchers
+// of the path (fused attention) take a slot for their role the same way the GEMM launcher does
+int tribe_internal_prof_before(int role, double flops, hipStream_t s);
+void tribe_internal_prof_after(int slot, hipStream_t s);
+
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

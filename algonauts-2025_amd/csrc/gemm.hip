@@ -545,13 +545,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
   if (0 < nk) stage(0, 0);
   if (1 < nk) stage(1, 1);
   if (2 < nk) stage(2, 2);
-  for (int t = 0; t < nk; ++t) {
+  bf16x8_t fa[2][2], fb[4][2];
+  auto sync_and_restage = [&](int t) {
     const int ahead = nk - 1 - t;   // K-tiles issued behind K-tile t (capped at 2 by the ring)
     if (ahead >= 2) wait_vmcnt<8>(); else if (ahead == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (t + 3 < nk) stage((t + 3) & 3, t + 3);
+  };
+  auto read_frags = [&](int t) {
     const char* base = smem + (t & 3) * STAGE_BYTES;
-    bf16x8_t fa[2][2], fb[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       fb[j][0] = *(const bf16x8_t*)(base + b_rd + j * 2048 + coff0);
@@ -564,6 +566,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read retired before the next barrier can be reached (restaging is then safe)
     __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -571,6 +575,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
       }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // The two waves of a SIMD (w and w + 4) run the same program; in lockstep both would read together and multiply together.  Waves
+  // 4..7 therefore run their MFMAs half an iteration late: after barrier t they multiply K-tile t-1 (fragments kept in registers
+  // across the barrier) while waves 0..3 read K-tile t, then read K-tile t while waves 0..3 multiply it (guide: "two waves per SIMD
+  // that run the same program with one barrier per block: try a stagger").
+#ifndef TRIBE_RING_NO_STAGGER
+  if (wave >= 4) {
+    for (int t = 0; t < nk; ++t) {
+      sync_and_restage(t);
+      if (t > 0) mma();
+      read_frags(t);
+    }
+    mma();
+  } else
+#endif
+  {
+    for (int t = 0; t < nk; ++t) {
+      sync_and_restage(t);
+      read_frags(t);
+      mma();
+    }
   }
   __builtin_amdgcn_s_barrier();   // the staging buffers become the epilogue's scratch: every wave is past its last fragment read
 
@@ -687,6 +713,9 @@ void prof_after(int slot, hipStream_t s) {
 }
 }  // namespace
 
+int tribe_internal_prof_before(int role, double flops, hipStream_t s) { return prof_before(role, flops, s); }
+void tribe_internal_prof_after(int slot, hipStream_t s) { prof_after(slot, s); }
+
 extern "C" int tribe_prof_begin(int32_t max_records) {
   std::lock_guard<std::mutex> lock(g_prof_mu);
   TRIBE_REQUIRE(max_records > 0, "tribe_prof_begin: max_records must be positive");
@@ -722,21 +751,36 @@ extern "C" int tribe_prof_end(int32_t n_roles, double* total_ms_host, int64_t* c
 }
 
 namespace {
+// 16 lanes per row (each 4 partials per step, shuffle reduction): at M = 4096 one thread per row was 16 workgroups walking 48-64 partials
+// serially -- 9.6 us per launch, 15 launches per forward = 1.9 % of the B = 4 step (profiles/r03_e_r1_kernel_stats.txt).
 __global__ __launch_bounds__(256) void rownorm_scale_kernel(const float* __restrict__ partial, int64_t rows, int64_t n_partial,
                                                             const float* __restrict__ g, float gain_scale, float eps, float* __restrict__ scale) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= rows) return;
-  const float* p = partial + m * n_partial;
+  const int sub = threadIdx.x & 15;
+  const int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   float ss = 0.f;
-  for (int64_t i = 0; i < n_partial; ++i) ss += p[i];
-  scale[m] = g[0] * gain_scale / fmaxf(sqrtf(ss), eps);
+  if (m < rows) {
+    const float* p = partial + m * n_partial;
+    if ((n_partial & 3) == 0 && (((uintptr_t)partial) & 15) == 0) {
+      for (int64_t i = sub * 4; i < n_partial; i += 64) {
+        const float4 v = *(const float4*)(p + i);
+        ss += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int64_t i = sub; i < n_partial; i += 16) ss += p[i];
+    }
+  }
+  ss += __shfl_xor(ss, 1, 64);
+  ss += __shfl_xor(ss, 2, 64);
+  ss += __shfl_xor(ss, 4, 64);
+  ss += __shfl_xor(ss, 8, 64);
+  if (m < rows && sub == 0) scale[m] = g[0] * gain_scale / fmaxf(sqrtf(ss), eps);
 }
 }  // namespace
 
 extern "C" int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partial, const float* g, float gain_scale, float eps,
                                        float* scale, void* stream) {
   TRIBE_REQUIRE(partial && g && scale && rows > 0 && n_partial > 0, "tribe_rownorm_scale_fwd: bad argument");
-  hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, rows, n_partial, g,
+  hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, n_partial, g,
                      gain_scale, eps, scale);
   TRIBE_LAUNCH_CHECK();
   return 0;

@@ -19,7 +19,7 @@ LIB_PATH = _HERE / "libtribe_hip.so"
 F32, BF16, F64 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU, ACT_GLU, ACT_GELU_BWD = 0, 1, 2, 3, 4, 5
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
-ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head"]
+ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head", "attention"]
 
 i64, i32, f32, vp, sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 

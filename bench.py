@@ -343,11 +343,12 @@ def run_rank(args) -> None:
 
     if rank == 0:
         fl = flops_per_tr()
-        # dominant kernel = the GEMM operator with the largest summed time inside the timed region
+        # dominant kernel = the operator (GEMM role or the fused attention) with the largest summed time inside the timed region
         by_kernel = _role_table(prof)
         dom = max(prof, key=lambda k: prof[k]["ms"])
         gemm_ms = sum(r["ms"] for r in prof.values()) / args.steps
-        roofline = {"bound": "mfma", "kernel": f"gemm_nt_256x256x64<{dom}>", "achieved": by_kernel[dom]["achieved_tflops"],
+        dom_name = "attn_fwd_wide384_kernel" if dom == "attention" else f"gemm_nt_256x256x64<{dom}>"
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": by_kernel[dom]["achieved_tflops"],
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": by_kernel[dom]["frac"], "traffic": None,
                     "traffic_source": None,
                     "avg_launch_ms": by_kernel[dom]["avg_ms"], "flops_per_launch": by_kernel[dom]["gflop_per_launch"] * 1e9,
@@ -383,6 +384,7 @@ def run_rank(args) -> None:
         }
         if world == 1 and not args.no_r1_point:
             out["r1_point"] = r1_point(model, fdims, device, ops)
+            out["config1_point"] = config1_point(device, ops)
         if world == 1 and not args.no_cpu_baseline:
             del model, batch
             torch.cuda.empty_cache()
@@ -416,6 +418,40 @@ def r1_point(model, fdims, device, ops, steps: int = 30, warmup: int = 5) -> dic
     return {"workload": f"B=4 sequences (4 subjects x R=1) x T={T}", "value": round(4 * T * steps / elapsed, 1), "unit": "TRs/s",
             "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "whole_path_tflops": round(4 * T * steps * fl["total"] / elapsed / 1e12, 1), "by_kernel": _role_table(prof)}
+
+
+def config1_point(device, ops, steps: int = 50, warmup: int = 10) -> dict:
+    """BASELINE config 1 on the GPU, outside the timed headline: text-only features (audio = video = None -> zero thirds of the
+    fusion, /root/reference/algonauts2025/model.py:143-144), one subject, B = 1 sequence of T = 128 TRs, the full-size encoder
+    (hidden 3072 x 8 layers, V = 1000) -- the GPU figure beside `cpu_baseline.legs.config1_text_only_B1_T128_*`.  128 rows give
+    every GEMM a single row of tiles: a launch-latency-bound point by construction, reported as measured."""
+    import torch
+
+    from algonauts2025.model import FmriEncoderConfig
+    from data_utils.dataloader import SegmentData
+
+    fd = {"text": (L, D), "audio": None, "video": None}
+    torch.manual_seed(0)
+    model = FmriEncoderConfig(n_subjects=1, hidden=HIDDEN, depth=DEPTH, heads=HEADS).build(fd, V, 128).eval().to(device)
+    g = torch.Generator(device=device).manual_seed(3)
+    data = {"text": torch.randn(1, L, D, 128, generator=g, device=device).to(torch.bfloat16),
+            "subject_id": torch.zeros(1, 1, dtype=torch.long, device=device)}
+    batch = SegmentData(data=data, segments=[None])
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(batch)
+        torch.cuda.synchronize()
+        ops.prof_begin(max_records=(steps + 1) * 128)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(batch)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = ops.prof_end()
+    del model
+    return {"workload": "BASELINE config 1: text-only, 1 subject, B=1 x T=128, hidden 3072 x 8 layers, V=1000 (audio / video absent)",
+            "value": round(128 * steps / elapsed, 1), "unit": "TRs/s", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "by_kernel": _role_table(prof)}
 
 
 def main() -> None:

@@ -46,7 +46,9 @@ enum tribe_bias_mode { TRIBE_BIAS_NONE = 0, TRIBE_BIAS_COL = 1, TRIBE_BIAS_ROW =
  * rocprofv3 --stats and in the tribe_prof_* event profile); arithmetic is identical for all roles */
 enum tribe_gemm_role {
   TRIBE_ROLE_GENERIC = 0, TRIBE_ROLE_PROJECTOR = 1, TRIBE_ROLE_QKV = 2, TRIBE_ROLE_ATTN_SCORES = 3, TRIBE_ROLE_ATTN_PV = 4,
-  TRIBE_ROLE_OUT_PROJ = 5, TRIBE_ROLE_FF1 = 6, TRIBE_ROLE_FF2 = 7, TRIBE_ROLE_VOXEL_HEAD = 8, TRIBE_ROLE_COUNT = 9
+  TRIBE_ROLE_OUT_PROJ = 5, TRIBE_ROLE_FF1 = 6, TRIBE_ROLE_FF2 = 7, TRIBE_ROLE_VOXEL_HEAD = 8,
+  TRIBE_ROLE_ATTENTION = 9, /* the fused attention launches (not a GEMM role: profile slot only; flops = 4 * T * dim_head per query row and head) */
+  TRIBE_ROLE_COUNT = 10
 };
 
 int tribe_version(void);

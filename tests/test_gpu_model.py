@@ -139,6 +139,37 @@ def test_missing_modality_and_text_only_config1():
     assert (got - want).norm() / want.norm() < 1e-2
 
 
+def test_config1_full_size_text_only():
+    """BASELINE config 1 AT FULL SIZE on the GPU: text-only cached features (L * D = 2 x 2048; audio = video = None
+    -> zero thirds of the fusion, /root/reference/algonauts2025/model.py:143-144), 1 subject, B = 1, T = 128 TRs, hidden 3072 x 8
+    layers, V = 1000 parcels, vs the fp32 CPU oracle.  The criterion is the relative L2 error of the predictions (< 1e-2: bf16
+    operands, f32 accumulation); per-voxel Pearson r over 128 samples is too noisy to carry a 3-dp criterion (its standard error
+    is ~0.09 at this sample count), so r is printed, not asserted.  M = 128 rows: every GEMM is a single row of 128 x 128 tiles
+    (the ring kernel); the fused attention runs one query block per head."""
+    from algonauts2025.model import FmriEncoderConfig
+
+    fdims = {"text": (2, 2048), "audio": None, "video": None}
+    V, T = 1000, 128
+    ref = tribe_ref.FmriEncoderRef(fdims, V, T, 1).eval()          # default dims: hidden 3072, depth 8, heads 8
+    with torch.no_grad():
+        tribe_ref.fill_params_(ref, seed=5)
+    m = FmriEncoderConfig(n_subjects=1).build(fdims, V, T).eval()
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda()
+    data = tribe_ref.synthetic_batch(1, T, {"text": (2, 2048)}, 1, seed=8)
+    with torch.no_grad():
+        want = ref(data)
+    got = m(_cuda_batch(data)).cpu()
+    assert got.shape == (1, V, T)
+    err = float((got - want).norm() / want.norm())
+    gc, wc = got[0] - got[0].mean(1, keepdim=True), want[0] - want[0].mean(1, keepdim=True)
+    r = (gc * wc).sum(1) / (gc.norm(dim=1) * wc.norm(dim=1))
+    print(f"config 1 full size: rel L2 {err:.3e}; per-voxel r(got, want) min {float(r.min()):.5f} (128 samples per voxel)")
+    assert err < 1e-2
+    # the same weights, trimodal call signature: absent modalities must not change the text-only result
+    assert torch.equal(m(_cuda_batch(data)).cpu(), got)
+
+
 def test_run_step_and_metrics_vs_oracle():
     """BrainModule.validation_step (pl_module.py:46-107,130-132): loss, streaming + grouped Pearson."""
     from algonauts2025.main import compute_multidim_pearson
