@@ -57,6 +57,9 @@ class FmriEncoderConfig(pydantic.BaseModel):
     max_timesteps: int = 1024
     rotary_interleaved: bool = True
     legacy_scalenorm: bool = False
+    # training: let the contrastive pass reuse the prediction pass's latents whenever its own dropout draw, the inputs and the
+    # parameters coincide (bit-identical loss; False = always re-run the encoder as model.py:228 does)
+    share_contrastive_latents: bool = True
 
     def build(self, feature_dims: dict[str, tuple[int, int] | None], n_outputs: int, n_output_timesteps: int) -> nn.Module:
         return FmriEncoder(feature_dims, n_outputs, n_output_timesteps, config=self)
@@ -194,8 +197,35 @@ class FmriEncoder(nn.Module):
         # Lightning runs training_step in train mode with grad enabled; evaluation (.eval()) keeps the fused fast path
         return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
-    def _latents_autograd(self, data: dict[str, torch.Tensor]) -> tuple[torch.Tensor, int, int]:
-        """aggregate_features + transformer_forward up to (not including) the final ScaleNorm: f32 [B*T, hidden]."""
+    def _latents_key(self, data: dict[str, torch.Tensor], dropped: list[str]) -> tuple:
+        """Everything the latents of a training pass depend on: the inputs (storage, version, shape), the modality-dropout draw and the
+        version of every parameter -- two passes with equal keys compute bit-identical latents (the kernels are deterministic)."""
+        inputs = tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in data.items()
+                       if (k in self.feature_dims or k == "subject_id") and isinstance(v, torch.Tensor))
+        return inputs, tuple(dropped), tuple(p._version for p in self.parameters())
+
+    def _latents_autograd(self, data: dict[str, torch.Tensor], share: str = "") -> tuple[torch.Tensor, int, int]:
+        """aggregate_features + transformer_forward up to (not including) the final ScaleNorm: f32 [B*T, hidden].
+
+        `share`: the reference's training step runs the encoder TWICE -- once for the prediction (model.py:113-123) and once more
+        inside compute_contrastive_loss -> get_brain_latents (model.py:177-182, 228), each with its own modality-dropout draw.
+        Whenever the two draws coincide (always at modality_dropout == 0; 19.5 % of the steps at the default 0.3 with three
+        modalities) the second pass recomputes the first bit for bit.  The prediction pass ("produce") therefore leaves its latents
+        behind and the contrastive pass ("consume") -- after drawing ITS dropout set from the same RNG stream the reference
+        consumes -- takes them when inputs, draw and parameter versions all match, and recomputes otherwise.  The loss is
+        bit-identical either way; autograd sums the two branches' gradients at the shared node."""
+        dropped = self._draw_modality_dropout()
+        key = self._latents_key(data, dropped) if share else None
+        if share == "consume":
+            kept, self._shared_latents = getattr(self, "_shared_latents", None), None
+            if kept is not None and kept[0] == key and self.config.share_contrastive_latents:
+                self.shared_latent_hits = getattr(self, "shared_latent_hits", 0) + 1
+                return kept[1]
+        out = self._latents_autograd_compute(data, dropped)
+        self._shared_latents = (key, out) if share == "produce" else None
+        return out
+
+    def _latents_autograd_compute(self, data: dict[str, torch.Tensor], dropped: list[str]) -> tuple[torch.Tensor, int, int]:
         from modeling_utils import autograd as ag
 
         cfg = self.config
@@ -211,7 +241,6 @@ class FmriEncoder(nn.Module):
             # reference behaviour: a hidden // n zero block cannot be summed with hidden-wide projections (model.py:143-144,163-164)
             raise RuntimeError(f"The size of tensor a ({self.hidden}) must match the size of tensor b ({self.hidden // n_mod}) "
                                "at non-singleton dimension 2")
-        dropped = self._draw_modality_dropout()
         slices = []
         for m in self.feature_dims.keys():
             if m not in self.projectors or m in dropped:  # model.py:143-144,158-159: zero block, no gradient
@@ -255,7 +284,7 @@ class FmriEncoder(nn.Module):
     def _forward_autograd(self, data: dict[str, torch.Tensor], pool_outputs: bool) -> torch.Tensor:
         from modeling_utils import autograd as ag
 
-        x, B, T = self._latents_autograd(data)
+        x, B, T = self._latents_autograd(data, share="produce" if self.config.contrastive_enabled else "")
         enc = self.encoder
         y = ag.ScaleNorm.apply(x, enc.final_norm.g, enc.final_norm.gain_scale, enc.final_norm.eps)
         out = ag.VoxelHead.apply(y.view(B, T, -1), self.predictor.weights, self.predictor.bias,
@@ -313,7 +342,7 @@ class FmriEncoder(nn.Module):
         and the symmetric InfoNCE -- all differentiable HIP functions."""
         from modeling_utils import autograd as ag
 
-        x, B, T = self._latents_autograd(data)
+        x, B, T = self._latents_autograd(data, share="consume")
         enc = self.encoder
         brain = ag.ScaleNorm.apply(x, enc.final_norm.g, enc.final_norm.gain_scale, enc.final_norm.eps, True)  # f32 [B*T, H]
         losses: dict[str, torch.Tensor] = {}

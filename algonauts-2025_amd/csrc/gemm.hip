@@ -577,11 +577,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
       }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // The two waves of a SIMD (w and w + 4) run the same program; in lockstep both would read together and multiply together.  Waves
-  // 4..7 therefore run their MFMAs half an iteration late: after barrier t they multiply K-tile t-1 (fragments kept in registers
-  // across the barrier) while waves 0..3 read K-tile t, then read K-tile t while waves 0..3 multiply it (guide: "two waves per SIMD
-  // that run the same program with one barrier per block: try a stagger").
-#ifndef TRIBE_RING_NO_STAGGER
+  // Tried and left off (-DTRIBE_RING_STAGGER): the two waves of a SIMD (w and w + 4) run the same program, so waves 4..7 were made to
+  // run their MFMAs half an iteration late (multiply K-tile t-1 while waves 0..3 read K-tile t; guide: "two waves per SIMD that run the
+  // same program with one barrier per block: try a stagger").  Same-box A/B (profiles/r03_f_gemm_tiles*.txt): projector 46.2 vs 44.1 us
+  // without, voxel head 36.7 vs 36.2 -- this loop waits on the L2 -> LDS stream, not on the matrix pipe, so there is nothing to overlap.
+#ifdef TRIBE_RING_STAGGER
   if (wave >= 4) {
     for (int t = 0; t < nk; ++t) {
       sync_and_restage(t);

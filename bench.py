@@ -432,7 +432,9 @@ def config1_point(device, ops, steps: int = 50, warmup: int = 10) -> dict:
 
     fd = {"text": (L, D), "audio": None, "video": None}
     torch.manual_seed(0)
-    model = FmriEncoderConfig(n_subjects=1, hidden=HIDDEN, depth=DEPTH, heads=HEADS).build(fd, V, 128).eval().to(device)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the constructor prints the reference's "no feature dimensions" warnings; stdout carries ONE JSON line
+        model = FmriEncoderConfig(n_subjects=1, hidden=HIDDEN, depth=DEPTH, heads=HEADS).build(fd, V, 128).eval().to(device)
     g = torch.Generator(device=device).manual_seed(3)
     data = {"text": torch.randn(1, L, D, 128, generator=g, device=device).to(torch.bfloat16),
             "subject_id": torch.zeros(1, 1, dtype=torch.long, device=device)}

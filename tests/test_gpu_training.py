@@ -6,6 +6,7 @@ product, f32 accumulation) vs an fp32 CPU graph -> per-tensor relative L2 error 
 import queue
 import time
 
+import numpy as np
 import pytest
 import torch
 
@@ -331,6 +332,59 @@ def test_training_step_with_contrastive_branch():
     bad = {k: v for k, v in worst.items() if v > 8e-2}
     assert not bad, f"gradient mismatch: {bad}"
     print("contrastive: max grad rel err", max(worst.values()))
+
+
+def test_contrastive_pass_shares_the_prediction_latents():
+    """with equal dropout draws the contrastive pass takes the prediction pass's latents instead of re-running the
+    encoder (model.py:228).  The loss must be BIT-identical to the two-pass form, the gradients equal up to the order of one f32 sum, and
+    a differing draw, changed inputs or stepped parameters must fall back to recomputation."""
+    from algonauts2025.model import FmriEncoderConfig
+    from algonauts2025.pl_module import BrainModule
+    from data_utils.dataloader import SegmentData
+    from modeling_utils.losses import TorchLossConfig
+
+    fdims = {"text": (2, 40), "audio": (2, 24), "video": (2, 33)}
+    V, Tout, S, B, T = 50, 10, 3, 4, 31
+    data = tribe_ref.synthetic_batch(B, T, fdims, S, seed=4)
+    fmri = torch.randn(B, V, Tout, generator=torch.Generator().manual_seed(9))
+    batch = SegmentData(data={**{k: v.cuda() for k, v in data.items()}, "fmri": fmri.cuda()}, segments=[None] * B)
+
+    def run(share: bool, dropout: float, seed: int):
+        torch.manual_seed(0)
+        model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=2, heads=4, contrastive_enabled=True, modality_dropout=dropout,
+                                  share_contrastive_latents=share).build(fdims, V, Tout).cuda().train()
+        bm = BrainModule(model, TorchLossConfig(name="MSELoss").build(), None, {})
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        loss = bm.training_step(batch, 0)
+        loss.backward()
+        return model, loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    m1, l1, g1 = run(True, 0.0, 1)
+    m0, l0, g0 = run(False, 0.0, 1)
+    assert getattr(m1, "shared_latent_hits", 0) == 1 and getattr(m0, "shared_latent_hits", 0) == 0
+    assert torch.equal(l1, l0), (float(l1), float(l0))
+    assert g1.keys() == g0.keys()
+    worst = max(_rel(g1[k].cpu(), g0[k].cpu()) for k in g1)
+    assert worst < 2e-2, worst   # one backward through the encoder for the summed gradient vs two summed at the parameters (bf16 dgrad operands)
+    # dropout 0.5: find a seed whose two draws differ and one whose draws coincide; sharing must follow the draws, the loss never changes
+    seen = set()
+    for seed in range(2, 40):
+        ms, ls, _ = run(True, 0.5, seed)
+        mn, ln, _ = run(False, 0.5, seed)
+        assert torch.equal(ls, ln), seed
+        seen.add(getattr(ms, "shared_latent_hits", 0))
+        if seen == {0, 1}:
+            break
+    assert seen == {0, 1}, seen
+    # a parameter written between the two passes invalidates the kept latents
+    torch.manual_seed(0)
+    model = FmriEncoderConfig(n_subjects=S, hidden=768, depth=2, heads=4, contrastive_enabled=True).build(fdims, V, Tout).cuda().train()
+    model(batch)
+    with torch.no_grad():
+        model.time_pos_embed.mul_(1.0)
+    model.compute_contrastive_loss(batch)
+    assert getattr(model, "shared_latent_hits", 0) == 0
 
 
 def test_hip_adam_matches_torch_adam():
