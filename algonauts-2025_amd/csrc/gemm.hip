@@ -281,6 +281,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
 #else
   const int krot = ((tn & 7) + (tm & 3)) % nk;
 #endif
+  // (Also tried, profiles/r03_h_gemm_kperm.txt: a cyclic shift inside every window of 8 K-tiles, which spreads the first touches evenly
+  // over the sharers instead of leaving them to the one that walks ahead -- FF1 / FF2 / QKV within +-0.7 % of the plain rotation.)
   auto ktile = [&](int t) { const int k = t + krot; return k >= nk ? k - nk : k; };
 #ifdef TRIBE_GEMM_STAMPS
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 from tribe_hip import _lib  # noqa: E402
 
-VARIANTS = ["base", "sprio", "nprio", "krot", "krotsp", "same"]
+VARIANTS = ["nokrot", "cur", "kperm"]
 libs = {}
 for v in VARIANTS:
     p = ROOT / "ab_tmp" / f"libgemm_abl_{v}.so"
@@ -23,7 +23,8 @@ for v in VARIANTS:
         h.tribe_gemm_bf16.restype = C.c_int
         libs[v] = h
 dev = torch.device("cuda")
-shapes = {"8192^3": (8192, 8192, 8192), "ff1 65536x12288x3072": (65536, 12288, 3072), "ff2 65536x3072x12288": (65536, 3072, 12288)}
+shapes = {"8192^3": (8192, 8192, 8192), "ff1 65536x12288x3072": (65536, 12288, 3072), "ff2 65536x3072x12288": (65536, 3072, 12288),
+          "qkv 65536x9216x3072": (65536, 9216, 3072), "ff1 B=4 4096x12288x3072": (4096, 12288, 3072)}
 for name, (M, N, K) in shapes.items():
     a = torch.randn(M, K, device=dev).bfloat16()
     b = torch.randn(N, K, device=dev).bfloat16()
