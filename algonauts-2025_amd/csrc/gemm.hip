@@ -613,15 +613,355 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
   });
 }
 
+
+// =============================================================================================
+// 256 x 256 x 64, ONE wave per SIMD (round 3): 4 waves, 128 x 128 per wave, accumulators in 256 AGPRs
+// =============================================================================================
+// VERDICT r2 item 1.  The 8-wave kernel above spends 58 % of a wave's loop outside its MFMA cluster and relies on the SIMD partner to
+// cover it; here a wave owns a whole SIMD and interleaves everything itself:
+//   * 64 accumulators of 16 x 16 (v_mfma_f32_16x16x32_bf16; the 32 x 32 x 16 shape holds a lower clock on this part, guide DVFS item 7)
+//     in compiler-allocated AGPRs ("+a" operands of inline-asm MFMAs: nothing in the loop does arithmetic on them, so hipcc never moves
+//     them), two fragment sets of 64 VGPRs (k-step 0 / 1 of a K-tile);
+//   * the K loop is a sequence of volatile asm statements in SOURCE ORDER -- hipcc's own schedule of the same loop ran 1.78 us per K-step
+//     against 1.36 for this one (scripts/probes/gemm_1wave_probe.hip, profiles/r03_*_gemm_1wave_probe.txt):
+//       phase B(t):  MFMAs (t, k-step 0)  ||  ds_reads (t, k-step 1), one per 2 MFMAs  ||  from MFMA 40 on, behind "lgkmcnt(0) + barrier"
+//                    (every wave has finished reading K-tile t), LDS-DMA pieces of K-tile t+2 into the buffer K-tile t occupied
+//       phase A(t+1): MFMAs (t, k-step 1) ||  more pieces  ||  at MFMA 16 "vmcnt(10) + barrier" (K-tile t+1 landed; the 10 youngest loads
+//                    are K-tile t+2's) and then the ds_reads (t+1, k-step 0)
+//     i.e. one LDS-DMA piece per 4 MFMAs, spread over 64 MFMAs; its last piece has 104 MFMAs of flight before its wait.  LDS reads per CU
+//     and K-tile fall from 192 KiB to 128 KiB; each wave reads 32 fragments for 128 MFMAs.
+//   * an LDS-DMA piece costs a lone wave ~35 cycles of MFMA issue (no partner wave to hide it), so the pieces are made as cheap as the ISA
+//     allows: global_load_lds with a SCALAR base + fixed 32-bit per-lane offsets (no vector arithmetic per piece), four pieces per M0
+//     write (the immediate offset steps the LDS and the memory address alike; the per-lane offsets compensate), no M0 save / restore.
+// Probe at 8192^3, same box, naive epilogue: 1574 vs 1505 TFLOP/s for the 8-wave kernel (+4.6 %); 2363 cycles per K-tile against 2048
+// of pure MFMA issue (the 8-wave kernel: ~2800), at a clock the chip lowers from 1.95 to 1.87 GHz as the stream gets denser.
+// NT form, any M / N / K % 64 == 0, every epilogue operator (the wave's 128 columns go through epilogue_fast in two halves of 64).
+#ifdef TRIBE_GEMM_STAMPS4W
+__device__ unsigned long long g_dbg_4w[8];
+#endif
+namespace w4 {
+constexpr int SMEM_BYTES = 2 * 65536;   // two K-tile buffers: A 32 KiB + B 32 KiB each
+constexpr int WB = 40, RB = 16, DPM = 4;                      // buffer-free barrier at MFMA WB of phase B, landed barrier at MFMA RB of phase A
+constexpr int NB_PIECES = (64 - WB) / DPM, NA1 = RB / DPM;    // pieces of K-tile t+2 issued before the landed barrier: 6 + 4
+static_assert((64 - WB) % DPM == 0 && RB % DPM == 0 && NB_PIECES + NA1 <= 16 && (16 - NB_PIECES) * DPM <= 64, "piece schedule");
+
+__device__ __forceinline__ void mfma(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rd(bf16x8_t& f, unsigned addr) {   // destination valid after the caller's own lgkmcnt wait (guide 5.7 item 1, form iii)
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+template <int IMM>
+__device__ __forceinline__ void glds(unsigned voff, const void* sbase) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void set_m0(unsigned v) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(v) : "memory"); }
+}  // namespace w4
+
+// The epilogue of the one-wave-per-SIMD kernel, specialised at COMPILE time by the operator set of the four encoder GEMMs it serves
+// (QKV: [row scale] -> bf16; FF1: [row scale] + column bias + GELU -> bf16; out-proj / FF2: [column bias] + scaled f32 residual in place
+// [+ bf16 copy + row sums of squares]).  epilogue_fast decides every operator at run time inside every sub-tile; with 64 sub-tiles per
+// wave that is ~70 000 instructions of mostly skipped code per kernel -- the instruction cache thrashed and a tile's epilogue took
+// 37 000 (bf16) to 72 000 (f32) cycles next to a 120 000-cycle K loop (stamps, profiles/r03_q_4w_lab.txt).  Here a sub-tile is ~60
+// instructions.  The launcher (w4_role_ok) only sends descriptors whose operators match the role; everything else keeps the 8-wave kernel.
+template <int OUT_BF16, int ROLE>
+__device__ __forceinline__ void epilogue_w4(const tribe_gemm_desc& g, f32x4_t (&acc)[8][8], int64_t mw, int64_t nw, int lane, char* lds_wave) {
+  constexpr bool BIAS = ROLE == TRIBE_ROLE_FF1 || ROLE == TRIBE_ROLE_FF2;
+  constexpr bool GELU = ROLE == TRIBE_ROLE_FF1;
+  constexpr bool RES = ROLE == TRIBE_ROLE_OUT_PROJ || ROLE == TRIBE_ROLE_FF2;
+  static_assert(OUT_BF16 == (RES ? 0 : 1), "QKV / FF1 write bf16, out-proj / FF2 the f32 residual stream");
+  // The K loop multiplies with the operands SWAPPED (B fragment as the MFMA's A operand), so a 16 x 16 accumulator holds the sub-tile
+  // transposed: register r of lane l is C[row = l & 15][column = 4 (l >> 4) + r] -- four CONSECUTIVE columns of one row per lane, the
+  // shape of a 16-byte / 8-byte store, with no quad transpose (16 vector instructions per sub-tile in the 8-wave kernel's epilogue; a
+  // lone wave per SIMD issues one vector instruction per ~4.5 cycles, so with 64 sub-tiles they would be 5000 cycles per tile).
+  // The B fragments are read with their row quads permuted (sigma = 0, 2, 1, 3: see the kernel), so lane group q = l >> 4 holds columns
+  // 4 sigma(q) .. + 3: lanes l and l + 32 own adjacent quads of a row, and for a PAIR of sub-tiles (j, j + 1) two v_permlane32_swap per
+  // pair hand the lower half-wave 8 consecutive bf16 columns of sub-tile j and the upper half those of j + 1: ONE 16-byte store per lane
+  // and pair instead of two 8-byte ones (guide T21: an epilogue's store tail is bound by store INSTRUCTIONS, not bytes).
+  const int q = lane >> 4;
+  const int64_t row0 = mw + (lane & 15);                                   // + 16 i
+  const int64_t col0 = nw + 4 * ((q & 1) * 2 + (q >> 1));                  // + 16 j   (4 sigma(q))
+  const int64_t colp = nw + 16 * (lane >> 5) + 8 * (q & 1);                // + 16 j (j even): first of the 8 columns the paired store writes
+  const bool has_rs = !RES && g.row_scale != nullptr, has_rsc = RES && g.res_scale != nullptr;
+  const bool has_cb = RES && g.c_bf16 != nullptr, has_ssq = RES && g.row_sumsq != nullptr;
+  const bool interior = mw + 128 <= g.M;   // wave-uniform
+  float4 bcol[8], rsc[8];
+  static_for<8>([&](auto jt) {
+    constexpr int j = decltype(jt)::value;
+    if constexpr (BIAS) bcol[j] = *(const float4*)(g.bias + col0 + j * 16);
+    if constexpr (RES) rsc[j] = has_rsc ? *(const float4*)(g.res_scale + col0 + j * 16) : make_float4(1.f, 1.f, 1.f, 1.f);
+  });
+  // The residual tile comes in by LDS-DMA, 16 sub-tiles (16 KiB per wave) per round, DOUBLE-BUFFERED: round r+1 is requested before round r
+  // is processed, and the wait for a round is COUNTED -- vmcnt counts loads and stores in issue order, so a full drain before every round
+  // would also wait for the previous round's 32 stores (that serialisation was 70 000 cycles per tile, stamps of profiles/r03_s_4w_lab.txt).
+  auto res_dma = [&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    static_for<2>([&](auto it) {
+      constexpr int i2 = decltype(it)::value;
+      int64_t row = row0 + (r * 2 + i2) * 16;
+      row = row < g.M ? row : g.M - 1;   // rows past M re-read a valid row (never stored): ALL 16 requests of a round are always issued,
+      const float* src = g.res + row * g.ldres + col0;   // the counted waits below depend on it
+      static_for<8>([&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 16), (lptr_t)(lds_wave + (r & 1) * 16384 + (i2 * 8 + j) * 1024), 16, 0, 0);
+      });
+    });
+  };
+  if constexpr (RES) {
+    res_dma(std::integral_constant<int, 0>{});
+    res_dma(std::integral_constant<int, 1>{});
+  }
+  static_for<4>([&](auto rt) {   // rounds of 2 sub-tile rows x 8 columns = 16 sub-tiles
+    constexpr int round = decltype(rt)::value;
+    float srow[2], ssq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    static_for<2>([&](auto it) {
+      const int64_t r = row0 + (round * 2 + decltype(it)::value) * 16;
+      srow[decltype(it)::value] = (has_rs && r < g.M) ? g.row_scale[r] : 1.0f;
+    });
+    if constexpr (RES) {
+      // A wait "vmcnt(N)" retires this round's requests iff at least N operations were issued after them.  Interior tile (every row of
+      // the wave < M: every sub-tile stores): younger = [round >= 1: the >= 16 stores of round - 1] + [round <= 2: the 16 requests of
+      // round + 1].  A tile that crosses M may skip whole stores, so it drains.
+      if (interior) {
+        if constexpr (round == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr (round < 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    uint2 pend = make_uint2(0u, 0u);
+    static_for<16>([&](auto st) {
+      constexpr int sidx = decltype(st)::value, i2 = sidx / 8, i = round * 2 + i2, j = sidx % 8;
+      const int64_t row = row0 + i * 16;
+      if (OUT_BF16 == 0 && row >= g.M) return;   // (bf16 roles: every lane takes part in the half-wave exchange; the store is masked below)
+      float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
+      if constexpr (!RES) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= srow[i2];
+      }
+      if constexpr (BIAS) { v[0] += bcol[j].x; v[1] += bcol[j].y; v[2] += bcol[j].z; v[3] += bcol[j].w; }
+      if constexpr (GELU) {
+        const f32x2_t lo = gelu_poly2(f32x2_t{v[0], v[1]}), hi = gelu_poly2(f32x2_t{v[2], v[3]});
+        v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+      }
+      if constexpr (RES) {
+        const float4 r = *(const float4*)(lds_wave + (round & 1) * 16384 + sidx * 1024 + lane * 16);
+        v[0] += r.x * rsc[j].x; v[1] += r.y * rsc[j].y; v[2] += r.z * rsc[j].z; v[3] += r.w * rsc[j].w;
+      }
+      const int64_t idx = row * g.ldc + col0 + j * 16;
+      if constexpr (OUT_BF16) {
+        u16x4_t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
+        const uint2 pk = __builtin_bit_cast(uint2, o);
+        if constexpr ((j & 1) == 0) {
+          pend = pk;                       // first sub-tile of the pair: keep
+        } else {
+          // vdst = the pair's first sub-tile, src = its second: the upper half of `pend` and the lower half of `pk` change places
+          const auto sx = __builtin_amdgcn_permlane32_swap(pend.x, pk.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(pend.y, pk.y, false, false);
+          // lower half: own quad of sub-tile j-1 | the partner's (the next quad of that sub-tile); upper half: the partner's quad of sub-tile j | own
+          if (row < g.M) *(uint4*)((unsigned short*)g.C + row * g.ldc + colp + (j - 1) * 16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      } else {
+        *(float4*)((float*)g.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        if (has_cb) {
+          u16x4_t o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
+          *(u16x4_t*)(g.c_bf16 + row * g.ld_c_bf16 + col0 + j * 16) = o;
+        }
+        ssq[i2][j / 4] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      }
+    });
+    if constexpr (RES && round + 2 < 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this round's LDS reads are retired: its half of the buffer takes round + 2
+      res_dma(std::integral_constant<int, round + 2>{});
+    }
+    if constexpr (RES) {
+      if (has_ssq) {   // one slot per 64 columns (the layout every other kernel writes): this wave fills two per row
+        static_for<4>([&](auto qt) {
+          constexpr int i2 = decltype(qt)::value / 2, hh = decltype(qt)::value % 2;
+          float t = ssq[i2][hh];
+          t += __shfl_xor(t, 16, 64);   // the four lanes l, l + 16, l + 32, l + 48 share a row
+          t += __shfl_xor(t, 32, 64);
+          const int64_t r = row0 + (round * 2 + i2) * 16;
+          if (lane < 16 && r < g.M) g.row_sumsq[r * g.ld_row_sumsq + (int64_t)((unsigned)nw >> 6) + hh] = t;
+        });
+      }
+    }
+  });
+}
+
+template <int OUT_BF16, int ROLE>
+__global__ __launch_bounds__(256, 1) void gemm_nt_4w256(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
+  using namespace w4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef TRIBE_GEMM_STAMPS4W
+  const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3
+  const int wr = wave >> 1, wc = wave & 1;                    // 2 x 2 waves of 128 x 128
+
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+
+  const int64_t z = blockIdx.y;
+  const int64_t b1 = z / g.batch0, b0 = z - b1 * g.batch0;
+  const int64_t b1g = g.gather1 ? g.gather1[b1] : b1;
+  const unsigned short* A = (const unsigned short*)g.A + (g.gather_a ? b1g : b1) * g.sA1 + b0 * g.sA0;
+  const unsigned short* B = (const unsigned short*)g.B + (g.gather_b ? b1g : b1) * g.sB1 + b0 * g.sB0;
+
+  // ---- LDS-DMA pieces: piece p (0..7 per operand) of this wave = 8 tile rows x 128 bytes, rows (wave * 8 + p) * 8 ..; row r of an operand
+  // tile at r * 128 with the 16-byte chunks XOR-swizzled by r & 7 on the SOURCE side.  Per-lane byte offsets from the tile's first row,
+  // shifted so that the immediate offset 1024 * (p & 3) of the instruction lands on the right memory row (see the header).
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  unsigned voff_a[8], voff_b[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int r = (wave * 8 + p) * 8 + srow;
+    const int64_t ra = (m0 + r < g.M ? m0 + r : g.M - 1) - m0, rb = (n0 + r < g.N ? n0 + r : g.N - 1) - n0;   // clamp: edge rows re-read a valid row
+    voff_a[p] = (unsigned)(ra * g.lda * 2 + schunk * 16 + 3072 - 1024 * (p & 3));
+    voff_b[p] = (unsigned)(rb * g.ldb * 2 + schunk * 16 + 3072 - 1024 * (p & 3));
+  }
+  // (the operand bases are wave-uniform by construction; readfirstlane makes that provable, so that they can be "s" operands -- guide T20)
+  auto uniform = [](const char* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+  };
+  const char* abase = uniform((const char*)(A + m0 * g.lda) - 3072);
+  const char* bbase = uniform((const char*)(B + n0 * g.ldb) - 3072);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+  unsigned dst_cur = lds0 + wave * 8192, dst_nxt = dst_cur + 65536;   // this wave's piece area in the buffer of K-tile t / t+1
+
+  f32x4_t acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const unsigned coff0 = ((fq ^ (frow & 7)) << 4);
+  // fragment read addresses of the current / next buffer, k-step 0 / 1 (fragment i at + i * 2048, an immediate)
+  unsigned ca0 = lds0 + (wr * 128 + frow) * 128 + coff0, ca1 = lds0 + (wr * 128 + frow) * 128 + (coff0 ^ 64);
+  // B fragment rows are read PERMUTED: MFMA row n' = 4 q + r (q = 0..3) holds tile row 4 sigma(q) + r, sigma = (0, 2, 1, 3), so that after the
+  // swapped-operand MFMA lanes l and l + 32 hold ADJACENT column quads of one row -- what the 16-byte bf16 store of epilogue_w4 needs
+  const int prow = (frow & 3) | ((frow & 4) << 1) | ((frow & 8) >> 1);
+  const unsigned bsw = (unsigned)(((fq ^ (prow & 7)) << 4));   // the source-side swizzle follows the row actually read
+  unsigned cb0 = lds0 + 32768 + (wc * 128 + prow) * 128 + bsw, cb1 = lds0 + 32768 + (wc * 128 + prow) * 128 + (bsw ^ 64);
+  unsigned na0 = ca0 + 65536, na1 = ca1 + 65536, nb0 = cb0 + 65536, nb1 = cb1 + 65536;
+
+  const int nk = (int)(g.K / BK);
+#ifdef TRIBE_GEMM_NO_KROT
+  const int krot = 0;
+#else
+  const int krot = ((tn & 7) + (tm & 3)) % nk;   // K rotation (see the 8-wave kernel)
+#endif
+  auto kbytes = [&](int t) { int k = t + krot; k = k >= nk ? k - nk : k; return (int64_t)k * (BK * 2); };
+
+  bf16x8_t fa[2][8], fb[2][8];   // [fragment set][fragment]
+  auto dma = [&](auto pc, unsigned dst, const char* ab, const char* bb) {
+    constexpr int p = decltype(pc)::value;   // 0..7 A pieces, 8..15 B pieces
+    if constexpr ((p & 3) == 0) set_m0(dst + (p & 4) * 1024 + (p >= 8 ? 32768 : 0));
+    glds<1024 * (p & 3)>(p >= 8 ? voff_b[p & 7] : voff_a[p & 7], p >= 8 ? bb : ab);
+  };
+  auto rd = [&](auto idx, int set, unsigned aaddr, unsigned baddr) {   // B fragments first: the next phase's first MFMAs need all eight
+    constexpr int r = decltype(idx)::value;
+    if constexpr (r < 8) lds_rd<r * 2048>(fb[set][r], baddr); else lds_rd<(r - 8) * 2048>(fa[set][r - 8], aaddr);
+  };
+
+  // ---- prologue: K-tile 0 landed, its k-step 0 in fragment set 0; K-tile 1 in flight ----
+  {
+    const char* a0p = abase + kbytes(0);
+    const char* b0p = bbase + kbytes(0);
+    static_for<16>([&](auto pc) { dma(pc, dst_cur, a0p, b0p); });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  static_for<16>([&](auto r) { rd(r, 0, ca0, cb0); });
+  if (nk > 1) {
+    const char* a1p = abase + kbytes(1);
+    const char* b1p = bbase + kbytes(1);
+    static_for<16>([&](auto pc) { dma(pc, dst_nxt, a1p, b1p); });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");   // (the nop: compiler-written accumulator zeros -> first asm MFMA)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // One K-tile: phase B then phase A.  DMA = 1: K-tile t+2 exists and is fetched (operand bases an / bn) into the buffer K-tile t leaves;
+  // DMA = 0 (the last two K-tiles): nothing to fetch, the landed wait is a full drain.  NEXT = 0 on the very last K-tile: no reads ahead.
+  auto ktile_body = [&](auto dma_c, auto next_c, const char* an, const char* bn) {
+    constexpr int DMA = decltype(dma_c)::value, NEXT = decltype(next_c)::value;
+    static_for<64>([&](auto mc) {   // ---- phase B: MFMAs (t, 0) on set 0
+      constexpr int mm = decltype(mc)::value, i = mm / 8, j = mm % 8;
+      if constexpr (mm == WB) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's reads of K-tile t are retired: its buffer may be overwritten
+      }
+      mfma(acc[i][j], fb[0][j], fa[0][i]);   // operands swapped: the sub-tile accumulates TRANSPOSED (see epilogue_w4)
+      if constexpr (mm % 2 == 1 && mm / 2 < 16) rd(std::integral_constant<int, mm / 2>{}, 1, ca1, cb1);
+      if constexpr (DMA && mm >= WB && (mm - WB) % DPM == DPM - 1) dma(std::integral_constant<int, (mm - WB) / DPM>{}, dst_cur, an, bn);
+    });
+    static_for<64>([&](auto mc) {   // ---- phase A: MFMAs (t, 1) on set 1
+      constexpr int mm = decltype(mc)::value, i = mm / 8, j = mm % 8;
+      if constexpr (mm == RB && NEXT) {
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_PIECES + NA1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // K-tile t+1 has landed for every wave
+      }
+      mfma(acc[i][j], fb[1][j], fa[1][i]);
+      if constexpr (NEXT && mm >= RB && (mm - RB) % 2 == 1 && (mm - RB) / 2 < 16) rd(std::integral_constant<int, (mm - RB) / 2>{}, 0, na0, nb0);
+      if constexpr (DMA && mm % DPM == DPM - 1 && NB_PIECES + mm / DPM < 16) dma(std::integral_constant<int, NB_PIECES + mm / DPM>{}, dst_cur, an, bn);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the next K-tile's buffer becomes the current one
+    unsigned t0;
+    t0 = ca0; ca0 = na0; na0 = t0;  t0 = ca1; ca1 = na1; na1 = t0;
+    t0 = cb0; cb0 = nb0; nb0 = t0;  t0 = cb1; cb1 = nb1; nb1 = t0;
+    t0 = dst_cur; dst_cur = dst_nxt; dst_nxt = t0;
+  };
+#ifdef TRIBE_GEMM_STAMPS4W   // diagnostic build only: cycles / 100-MHz ticks of workgroup 0's K loop -> tribe_debug_4w (never quote its run time)
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int t = 0;
+  for (; t + 2 < nk; ++t) ktile_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, abase + kbytes(t + 2), bbase + kbytes(t + 2));
+  if (t + 1 < nk) { ktile_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, abase, bbase); ++t; }
+  ktile_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, abase, bbase);
+#ifdef TRIBE_GEMM_STAMPS4W
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    g_dbg_4w[0] = __builtin_amdgcn_s_memtime() - st_c0;
+    g_dbg_4w[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    g_dbg_4w[2] = (unsigned long long)nk;
+    g_dbg_4w[3] = st_c0 - st_entry;   // prologue: entry -> K loop
+  }
+  const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last asm MFMAs -> compiler reads of the accumulators
+  __builtin_amdgcn_s_barrier();                       // every wave is past its last fragment read: the buffers become the epilogue's scratch
+
+  // (the launcher guarantees: un-batched, N a multiple of 256, 16-byte aligned operands, the operator set of ROLE -- w4_role_ok)
+  epilogue_w4<OUT_BF16, ROLE>(g, acc, m0 + wr * 128, n0 + wc * 128, lane, smem + wave * 32768);
+#ifdef TRIBE_GEMM_STAMPS4W
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_dbg_4w[4] = __builtin_amdgcn_s_memtime() - st_e0;   // epilogue incl. store drain
+#endif
+}
+
 }  // namespace
 
 
 
 
 // ---------------------------------------------------------------------------------------------
-// Launch tables.  gemm.hip is compiled in three parts (Makefile: -DTRIBE_GEMM_PART=0 / 1 / 2 -> gemm.o, gemm_p1.o, gemm_p2.o) so that
-// the instantiations build side by side: part 0 = the C entry points + the 256 x 256 kernel (and its transposed-operand form),
-// part 1 = the 256 x 192 kernel, part 2 = the two 128 x 128 kernels.  A build without the macro compiles everything in one unit.
+// Launch tables.  gemm.hip is compiled in four parts (Makefile: -DTRIBE_GEMM_PART=0 .. 3 -> gemm.o, gemm_p1.o, gemm_p2.o, gemm_p3.o) so that
+// the instantiations build side by side: part 0 = the C entry points + the 8-wave 256 x 256 kernel (and its transposed-operand form),
+// part 1 = the 256 x 192 kernel, part 2 = the two 128 x 128 kernels, part 3 = the 4-wave 256 x 256 kernel.  A build without the macro compiles everything in one unit.
 // ROLE only gives each call site of the path its own kernel symbol, so that rocprofv3 --stats reports per-operator rows.
 // ---------------------------------------------------------------------------------------------
 #ifndef TRIBE_GEMM_PART
@@ -630,7 +970,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
 #define TRIBE_GEMM_HAS_PART(p) (TRIBE_GEMM_PART < 0 || TRIBE_GEMM_PART == (p))
 
 namespace tribe_gemm_detail {
-enum { KIND_SMALL = 0, KIND_BIG = 1, KIND_RING = 2 };
+enum { KIND_SMALL = 0, KIND_BIG = 1, KIND_RING = 2, KIND_BIG4W = 3 };
 // (output dtype, role symbol) pairs that exist as kernels; every other combination runs under the GENERIC symbol
 #define TRIBE_GEMM_PAIRS(X)                                                                                            \
   X(0, 1, TRIBE_ROLE_GENERIC) X(1, 0, TRIBE_ROLE_GENERIC) X(2, 1, TRIBE_ROLE_EXT) X(3, 0, TRIBE_ROLE_EXT)              \
@@ -640,6 +980,7 @@ void launch_big4(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, i
 void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_big3(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_ring(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+void launch_4w(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_small(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 
 // the dynamic-LDS attribute is set once per kernel AND device (one process may drive several GPUs)
@@ -682,6 +1023,20 @@ TRIBE_GEMM_TABLE(launch_ring)
 #define TRIBE_GEMM_CASE_launch_small(idx, bf, role) \
   case idx: launch_k<gemm_nt_128x128x64<bf, role>, 256, small::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
 TRIBE_GEMM_TABLE(launch_small)
+#endif
+#if TRIBE_GEMM_HAS_PART(3)
+#ifdef TRIBE_GEMM_STAMPS4W
+extern "C" int tribe_debug_4w(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_4w), 64); }
+#endif
+void launch_4w(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n) {
+  switch (pair) {   // the four encoder GEMMs with compile-time operator sets (epilogue_w4)
+    case 5: launch_k<gemm_nt_4w256<1, TRIBE_ROLE_QKV>, 256, w4::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+    case 8: launch_k<gemm_nt_4w256<0, TRIBE_ROLE_OUT_PROJ>, 256, w4::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+    case 9: launch_k<gemm_nt_4w256<1, TRIBE_ROLE_FF1>, 256, w4::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+    case 10: launch_k<gemm_nt_4w256<0, TRIBE_ROLE_FF2>, 256, w4::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+    default: break;
+  }
+}
 #endif
 }  // namespace tribe_gemm_detail
 
@@ -789,9 +1144,31 @@ extern "C" int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64
 }
 
 
+#ifndef TRIBE_GEMM_4W_DEFAULT
+#define TRIBE_GEMM_4W_DEFAULT 1
+#endif
 namespace tribe_gemm_detail {
 // Which kernel and tile a launch gets.  sumsq_cols = columns per row_sumsq slot (one slot per wave column group).
 struct GemmPlan { int kind, bm, bn, sumsq_cols; };
+// true when the descriptor carries exactly the operator set epilogue_w4 compiles for its role (and the alignments its vector accesses need)
+static bool w4_role_ok(const tribe_gemm_desc* d) {
+  const bool res_role = d->role == TRIBE_ROLE_OUT_PROJ || d->role == TRIBE_ROLE_FF2;
+  const bool bf_role = d->role == TRIBE_ROLE_QKV || d->role == TRIBE_ROLE_FF1;
+  if (!res_role && !bf_role) return false;
+  if (d->batch1 * d->batch0 != 1 || d->trans_ab || d->gather1 || d->N % 256 != 0 || d->rowadd || d->gadd || d->aux) return false;
+  if (d->c_dtype != (bf_role ? TRIBE_BF16 : TRIBE_F32) || d->ldc % 4 != 0 || ((uintptr_t)d->C % 16) != 0) return false;
+  const bool wants_bias = d->role == TRIBE_ROLE_FF1 || d->role == TRIBE_ROLE_FF2;
+  if (wants_bias ? (d->bias_mode != TRIBE_BIAS_COL || !d->bias || ((uintptr_t)d->bias % 16) != 0) : d->bias_mode != TRIBE_BIAS_NONE) return false;
+  if (d->act != (d->role == TRIBE_ROLE_FF1 ? TRIBE_ACT_GELU : TRIBE_ACT_NONE)) return false;
+  if (res_role) {
+    if (!d->res || d->ldres % 4 != 0 || ((uintptr_t)d->res % 16) != 0 || d->row_scale) return false;
+    if (d->res_scale && ((uintptr_t)d->res_scale % 16) != 0) return false;
+    if (d->c_bf16 && (d->ld_c_bf16 % 4 != 0 || ((uintptr_t)d->c_bf16 % 8) != 0)) return false;
+  } else {
+    if (d->res || d->res_scale || d->c_bf16 || d->row_sumsq) return false;
+  }
+  return (int64_t)255 * (d->lda > d->ldb ? d->lda : d->ldb) * 2 + 8192 < (1ll << 32);   // 32-bit per-lane offsets of the LDS-DMA pieces
+}
 static GemmPlan gemm_plan(const tribe_gemm_desc* d) {
   const int64_t nz = d->batch1 * d->batch0;
   auto tiles = [&](int64_t bm, int64_t bn) { return ((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn) * nz; };
@@ -808,7 +1185,7 @@ static GemmPlan gemm_plan(const tribe_gemm_desc* d) {
   if (use_big && t128 >= 512 && (double)t128 * 128 * 128 * 1.25 <= (double)t256 * 256 * 256) use_big = 0;
   if (fused_norm && d->N % 128 != 0) use_big = 1;   // (the launcher then reports the N it needs)
   if (d->tile_hint == 1 || d->tile_hint == 3) use_big = 0;
-  if (d->tile_hint == 2 || d->tile_hint == 4) use_big = 1;
+  if (d->tile_hint == 2 || d->tile_hint == 4 || d->tile_hint == 5) use_big = 1;
   if (d->trans_ab) return {KIND_BIG, 256, 256, 64};
   if (!use_big) {
     // one workgroup per CU or fewer: the ring kernel (three K-tiles in flight); more: the double-buffered kernel, whose two or three
@@ -827,6 +1204,13 @@ static GemmPlan gemm_plan(const tribe_gemm_desc* d) {
     if (cost3 < 0.95 * cost4) bn = 192;
   }
   if (fused_norm && d->N % bn != 0) bn = (d->N % 256 == 0) ? 256 : 192;
+  // 256 x 256 tiles of the four encoder GEMMs: the one-wave-per-SIMD kernel, whose epilogue is compiled for exactly their operator sets
+  // (tile_hint 2 keeps the 8-wave form for A/B runs; everything else -- other roles, batched, transposed operands -- stays 8-wave)
+  // Default: QKV and FF1 (bf16 outputs: +4.1 % / +3.2 % over the 8-wave kernel with their model epilogues at B = 64, +3 ... 4 % at B = 4,
+  // profiles/r03_u_4w_lab.txt); the residual-stream GEMMs (out-proj, FF2) keep the 8-wave kernel, whose two waves per SIMD overlap the
+  // 640 KiB of epilogue traffic per tile better (-1 ... -3 % for the 4-wave form there); tile_hint 5 forces the 4-wave kernel for all four.
+  const bool w4_default = TRIBE_GEMM_4W_DEFAULT && d->tile_hint == 0 && (d->role == TRIBE_ROLE_QKV || d->role == TRIBE_ROLE_FF1);
+  if (bn == 256 && (d->tile_hint == 5 || w4_default) && w4_role_ok(d)) return {KIND_BIG4W, 256, 256, 64};
   return {KIND_BIG, 256, bn, bn / 4};
 }
 }  // namespace tribe_gemm_detail
@@ -912,7 +1296,8 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
     }
   }
   using namespace tribe_gemm_detail;
-  if (plan.kind == KIND_BIG && plan.bn == 192) launch_big3(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
+  if (plan.kind == KIND_BIG4W) launch_4w(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
+  else if (plan.kind == KIND_BIG && plan.bn == 192) launch_big3(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
   else if (plan.kind == KIND_BIG) launch_big4(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
   else if (plan.kind == KIND_RING) launch_ring(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
   else launch_small(pair, grid, s, d, (int)tiles_m, (int)tiles_n);

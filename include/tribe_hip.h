@@ -90,7 +90,7 @@ typedef struct tribe_gemm_desc {
   void* aux; int64_t ld_aux;
   int32_t gather_b;        /* gather1 also replaces b1 for the B operand */
   int32_t role;            /* enum tribe_gemm_role */
-  int32_t tile_hint;       /* 0 = automatic; tests / tuning: 1 = 128x128 double-buffered, 2 = 256x256, 3 = 128x128 ring, 4 = 256x192 */
+  int32_t tile_hint;       /* 0 = automatic; tests / tuning: 1 = 128x128 double-buffered, 2 = 256x256, 3 = 128x128 ring, 4 = 256x192, 5 = 256x256 one-wave-per-SIMD */
   /* 1 = the operands are given TRANSPOSED: A is At [K, M] (lda >= M), B is Bt [K, N] (ldb >= N), C[m][n] = sum_k At[k][m] Bt[k][n] --
    * the weight gradient dW = dY^T X straight from the row-major dY [tokens, N_out] and X [tokens, K_in] the forward produced, without
    * the explicit transposes (torch.nn.functional.linear's backward in the reference).  M, N multiples of 8; plain epilogue only. */

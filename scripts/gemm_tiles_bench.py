@@ -22,6 +22,7 @@ SHAPES = [  # name, batch, M, N, K, out dtype
     ("w2v 3000x1024x1024", 1, 3000, 1024, 1024, torch.bfloat16), ("w2v ffn 24000x4096x1024", 1, 24000, 4096, 1024, torch.bfloat16),
     ("llama qkv 8192x5120x3072", 1, 8192, 5120, 3072, torch.bfloat16), ("llama down 8192x3072x8192", 1, 8192, 3072, 8192, torch.float32),
     ("llama 1024 tok 1024x3072x3072", 1, 1024, 3072, 3072, torch.float32),
+    ("ff1 B=64", 1, 65536, 12288, 3072, torch.bfloat16), ("ff2 B=64", 1, 65536, 3072, 12288, torch.float32), ("8192^3", 1, 8192, 8192, 8192, torch.bfloat16),
 ]
 for name, Z, M, N, K, odt in SHAPES:
     Kp = (K + 63) // 64 * 64
@@ -30,7 +31,7 @@ for name, Z, M, N, K, odt in SHAPES:
     if Z == 1:
         a, b = a[0], b[0]
     out = torch.empty((Z, M, N) if Z > 1 else (M, N), device=dev, dtype=odt)
-    hints = [0, 1, 2, 3, 4]
+    hints = [0, 1, 2, 3, 4, 5]
     times = {h: [] for h in hints}
     reps = 10
     for rnd in range(5):
@@ -47,6 +48,6 @@ for name, Z, M, N, K, odt in SHAPES:
     med = {h: statistics.median(times[h]) for h in hints}
     fl = 2.0 * Z * M * N * K
     best = min((h for h in hints if h), key=lambda h: med[h])
-    print(f"{name:32s} auto {med[0]:8.1f} us ({fl / med[0] / 1e6:6.0f} TF) | dbuf128 {med[1]:8.1f}  256^2 {med[2]:8.1f}  ring128 {med[3]:8.1f}  256x192 {med[4]:8.1f} | "
+    print(f"{name:32s} auto {med[0]:8.1f} us ({fl / med[0] / 1e6:6.0f} TF) | dbuf128 {med[1]:8.1f}  256^2 {med[2]:8.1f}  ring128 {med[3]:8.1f}  256x192 {med[4]:8.1f}  4w256 {med[5]:8.1f} | "
           f"best = hint {best}{'' if med[0] <= 1.03 * med[best] else '   <-- auto is not the best'}", flush=True)
     del a, b, out

@@ -39,7 +39,7 @@ def test_gemm_identity_asymmetric(ops):
     torch.testing.assert_close(out.cpu(), b.t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("tile_hint", [1, 2, 3, 4])  # 1 = 128x128 double-buffered, 2 = 256x256 (counted-vmcnt pipeline), 3 = 128x128 ring, 4 = 256x192
+@pytest.mark.parametrize("tile_hint", [1, 2, 3, 4])  # 1 = 128x128 double-buffered, 2 = 256x256 8-wave (counted-vmcnt pipeline), 3 = 128x128 ring, 4 = 256x192
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (77, 1000, 192), (1000, 298, 3072), (4, 5, 64), (129, 129, 64),
                                    (256, 256, 64), (512, 768, 320), (257, 511, 128), (1024, 1024, 384)])
 def test_gemm_shapes(ops, M, N, K, tile_hint):
@@ -209,6 +209,73 @@ def test_gemm_fused_norm_operands(ops, hint):
     _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(c), s), "gemm")
     want = torch.nn.functional.gelu((a.double() @ b.double().t()) * scale.double()[:, None] + bias.double())
     torch.testing.assert_close(out.cpu().double(), want, rtol=2**-7, atol=2e-3)
+
+
+@pytest.mark.parametrize("role", ["qkv", "ff1", "out_proj", "ff2"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1001, 768, 192), (512, 256, 1024), (70, 512, 256)])
+def test_gemm_one_wave_per_simd_roles(ops, role, M, N, K):
+    """The 256 x 256 one-wave-per-SIMD kernel (tile_hint 5) exists for the four encoder GEMMs, each with its compile-time operator set
+    (QKV: [row scale] -> bf16; FF1: [row scale] + bias + GELU -> bf16; out-proj / FF2: [bias] + scaled residual in place [+ bf16 copy + row
+    sums of squares]).  K = 64 ... 1024 covers the K loop's one-, two- and many-tile paths; M = 70 / 300 / 1001 end inside a tile.  The same
+    descriptor through the 8-wave kernel (tile_hint 2) must agree to f32 summation order, and repeated launches bit for bit."""
+    import ctypes as C
+
+    from tribe_hip import _lib
+
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / K**0.5)
+    bias, rs, scale = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.rand(M, generator=g) + 0.5
+    res = torch.randn(M, N, generator=g)
+    A, B, biasd, rsd, sd = _dev(a).bfloat16(), _dev(b).bfloat16(), _dev(bias), _dev(rs), _dev(scale)
+    res_role = role in ("out_proj", "ff2")
+    base = a.double() @ b.double().t()
+    s = torch.cuda.current_stream().cuda_stream
+    for variant in range(2):   # 0: without the optional operands, 1: with them
+        outs = {}
+        for hint in (2, 5):
+            d = _lib.GemmDesc()
+            d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, 1, 1
+            d.A, d.lda, d.B, d.ldb = A.data_ptr(), K, B.data_ptr(), K
+            d.alpha, d.tile_hint, d.role = 1.0, hint, _lib.ROLES.index(role)
+            if res_role:
+                x = _dev(res.clone())
+                xb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+                ssq = torch.zeros(M, N // 32, device="cuda")
+                d.C, d.ldc, d.c_dtype = x.data_ptr(), N, _lib.F32
+                d.res, d.ldres = x.data_ptr(), N
+                if role == "ff2":
+                    d.bias, d.bias_mode = biasd.data_ptr(), _lib.BIAS_COL
+                if variant:
+                    d.res_scale = rsd.data_ptr()
+                    d.c_bf16, d.ld_c_bf16, d.row_sumsq = xb.data_ptr(), N, ssq.data_ptr()
+                    d.ld_row_sumsq = _lib.lib().tribe_gemm_sumsq_slots(C.byref(d))
+                    assert d.ld_row_sumsq == N // 64
+                _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(d), s), "gemm")
+                want = base + (bias.double() if role == "ff2" else 0.0) + res.double() * (rs.double() if variant else 1.0)
+                torch.testing.assert_close(x.cpu().double(), want, rtol=1e-5, atol=1e-4)
+                if variant:
+                    assert torch.equal(xb.cpu(), x.cpu().bfloat16())
+                    part = ssq.flatten()[: M * (N // 64)].view(M, N // 64).cpu().double()   # (the kernel's row pitch is the slot count)
+                    torch.testing.assert_close(part.sum(1), (x.cpu().double() ** 2).sum(1), rtol=1e-5, atol=1e-4)
+                outs[hint] = x.cpu()
+            else:
+                out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+                d.C, d.ldc, d.c_dtype = out.data_ptr(), N, _lib.BF16
+                if role == "ff1":
+                    d.bias, d.bias_mode, d.act = biasd.data_ptr(), _lib.BIAS_COL, _lib.ACT_GELU
+                if variant:
+                    d.row_scale = sd.data_ptr()
+                _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(d), s), "gemm")
+                want = base * (scale.double()[:, None] if variant else 1.0)
+                if role == "ff1":
+                    want = torch.nn.functional.gelu(want + bias.double())
+                torch.testing.assert_close(out.cpu().double(), want, rtol=2**-7, atol=2e-3)
+                first = out.clone()
+                for _ in range(5):
+                    _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(d), s), "gemm")
+                    assert torch.equal(out, first)
+                outs[hint] = out.cpu().float()
+        torch.testing.assert_close(outs[5], outs[2], rtol=2**-7, atol=2e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64])
