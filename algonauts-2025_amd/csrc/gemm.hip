@@ -635,7 +635,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
 //     write (the immediate offset steps the LDS and the memory address alike; the per-lane offsets compensate), no M0 save / restore.
 // Probe at 8192^3, same box, naive epilogue: 1574 vs 1505 TFLOP/s for the 8-wave kernel (+4.6 %); 2363 cycles per K-tile against 2048
 // of pure MFMA issue (the 8-wave kernel: ~2800), at a clock the chip lowers from 1.95 to 1.87 GHz as the stream gets denser.
-// NT form, any M / N / K % 64 == 0, every epilogue operator (the wave's 128 columns go through epilogue_fast in two halves of 64).
+// Tried and dropped (profiles/r03_w_4w_lab_persistent.txt): a PERSISTENT form (one workgroup per CU walking the tiles, the next tile's first two
+// K-tiles requested before the current tile's epilogue stores): QKV +2.5 % instead of +4.1 % over the 8-wave kernel, FF1 +1.0 % instead of
+// +3.2 % -- the dispatcher already starts the next workgroup while the previous one's stores drain, and a static tile walk gives up its
+// load balancing over 36 - 48 tiles per CU.
+// NT form, K % 64 == 0, N % 256 == 0, the operator sets of the four encoder GEMMs (epilogue_w4); everything else keeps the 8-wave kernel.
 #ifdef TRIBE_GEMM_STAMPS4W
 __device__ unsigned long long g_dbg_4w[8];
 #endif
