@@ -3,7 +3,7 @@
   * no compiler-generated v_accvgpr_* or MFMA outside the ASMSTART / ASMEND blocks (a0..a191 hold O^T and belong to the asm
     statements of attn_acc_regs.h; the compiler must not allocate accumulator registers of its own),
   * prints the register budget and the instruction mix of the key loop.
-Usage: python scripts/check_attn_wide_isa.py [--no-gemm | --attention-only]
+Usage: python scripts/check_attn_wide_isa.py [--no-gemm | --attention-only | --gemm4w-isa FILE.s]
 (--attention-only: attention.hip alone -- the Makefile runs this after compiling attention.o and fails the build on a violation.)"""
 import re
 import subprocess
@@ -32,6 +32,45 @@ def device_isa(sources: list[str]) -> dict[str, str]:
             isa[src] = out.read_text()
         return isa
 
+
+def audit_gemm4w(isa_text: str) -> bool:
+    """The one-wave-per-SIMD GEMM kernel (gemm.hip part 3) keeps 64 accumulators in compiler-allocated AGPRs behind "+a" operands of inline-asm
+    MFMAs: it must compile without scratch, with all 256 AGPRs, and between the first and the last MFMA of a kernel the compiler must
+    neither move accumulators (v_accvgpr_*) nor touch scratch."""
+    good = True
+    found = re.findall(r"\.amdhsa_kernel (_ZN\S*gemm_nt_4w256\S*)\n(.*?)\.end_amdhsa_kernel", isa_text, re.S)
+    if not found:
+        print("FAIL: no gemm_nt_4w256 kernel in the ISA")
+        return False
+    for name, body in found:
+        meta = {k: int(v) for k, v in re.findall(r"\.amdhsa_(next_free_vgpr|accum_offset|private_segment_fixed_size)\s+(\d+)", body)}
+        m = re.search(rf"^{re.escape(name)}:(.*?)^\s*s_endpgm", isa_text, re.S | re.M)
+        code = m.group(1).splitlines() if m else []
+        # basic blocks (split at labels and branches): a block that issues MFMAs is K-loop code and must hold no accumulator moves or scratch
+        blocks, cur_block = [], []
+        for ln in code:
+            t = ln.strip()
+            if t.startswith(".LBB") or re.match(r"s_c?branch", t):
+                blocks.append(cur_block)
+                cur_block = []
+            else:
+                cur_block.append(t)
+        blocks.append(cur_block)
+        n_mfma = sum(1 for ln in code if "v_mfma" in ln)
+        bad = [t for blk in blocks if any("v_mfma" in t for t in blk) for t in blk if re.search(r"\bv_accvgpr|scratch_", t)] if n_mfma else ["no MFMA found"]
+        line = f"gemm_nt_4w256 [{name[-34:]}]: {meta}, {n_mfma} MFMAs"
+        if meta.get("private_segment_fixed_size", 1) or meta.get("next_free_vgpr", 9999) > 512 or meta.get("next_free_vgpr", 0) - meta.get("accum_offset", 0) < 256 or bad:
+            print("FAIL (scratch, registers, or accumulator traffic inside the K loop):", line, *bad[:5], sep="\n  ")
+            good = False
+        else:
+            print(line)
+    return good
+
+
+if "--gemm4w-isa" in sys.argv[1:]:   # audit a compiled ISA file (the Makefile passes the -save-temps output of gemm.hip part 3)
+    ok4 = audit_gemm4w(Path(sys.argv[sys.argv.index("--gemm4w-isa") + 1]).read_text())
+    print("OK: one-wave-per-SIMD GEMM kernels keep their accumulators in place" if ok4 else "gemm4w audit FAILED")
+    sys.exit(0 if ok4 else 1)
 
 ATTN_ONLY = "--attention-only" in sys.argv[1:]
 WITH_GEMM = "--no-gemm" not in sys.argv[1:] and not ATTN_ONLY   # gemm.hip takes two minutes to compile (its role instantiations); the unit test skips it
