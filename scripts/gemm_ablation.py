@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 from tribe_hip import _lib  # noqa: E402
 
-VARIANTS = ["nokrot", "cur", "kperm"]
+VARIANTS = ["base", "nolds", "nostage", "bare", "nomfma", "dmaonly", "same", "dmasame"]
 libs = {}
 for v in VARIANTS:
     p = ROOT / "ab_tmp" / f"libgemm_abl_{v}.so"

@@ -1,5 +1,5 @@
 """Tile-kernel choice per GEMM shape: times every tile kernel (tile_hint 1 = 128^2 double-buffered, 2 = 256^2, 3 = 128^2 ring, 4 = 256 x 192)
-against the launcher's automatic choice (hint 0) on the shapes of the BASELINE config at B = 4 (M = 4096) and of the extractors,
+against the launcher's automatic choice (hint 0; the one-wave-per-SIMD kernel exists for the four encoder roles only and has its own A/B, scripts/gemm_4w_lab.py) on the shapes of the BASELINE config at B = 4 (M = 4096) and of the extractors,
 interleaved in one process on random operands.  Usage (GPU box): python scripts/gemm_tiles_bench.py > gpurun_out/gemm_tiles.txt"""
 import statistics
 import sys
@@ -31,7 +31,7 @@ for name, Z, M, N, K, odt in SHAPES:
     if Z == 1:
         a, b = a[0], b[0]
     out = torch.empty((Z, M, N) if Z > 1 else (M, N), device=dev, dtype=odt)
-    hints = [0, 1, 2, 3, 4, 5]
+    hints = [0, 1, 2, 3, 4]
     times = {h: [] for h in hints}
     reps = 10
     for rnd in range(5):
@@ -48,6 +48,6 @@ for name, Z, M, N, K, odt in SHAPES:
     med = {h: statistics.median(times[h]) for h in hints}
     fl = 2.0 * Z * M * N * K
     best = min((h for h in hints if h), key=lambda h: med[h])
-    print(f"{name:32s} auto {med[0]:8.1f} us ({fl / med[0] / 1e6:6.0f} TF) | dbuf128 {med[1]:8.1f}  256^2 {med[2]:8.1f}  ring128 {med[3]:8.1f}  256x192 {med[4]:8.1f}  4w256 {med[5]:8.1f} | "
+    print(f"{name:32s} auto {med[0]:8.1f} us ({fl / med[0] / 1e6:6.0f} TF) | dbuf128 {med[1]:8.1f}  256^2 {med[2]:8.1f}  ring128 {med[3]:8.1f}  256x192 {med[4]:8.1f} | "
           f"best = hint {best}{'' if med[0] <= 1.03 * med[best] else '   <-- auto is not the best'}", flush=True)
     del a, b, out
