@@ -431,14 +431,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wide384_kernel(const AttnArgs
     st_src[i] = swz_wide(p % C::CHUNKS, st_row[i]) * 8;   // element offset of the SOURCE chunk inside the row
     st_off[i] = st_row[i] * (int)ld + st_src[i];
   }
-  // One 1-KiB piece of the K (which = 0) or V (which = 1) tile that starts at key0, into ring slot `slot` of that operand
+  // One 1-KiB piece of the K (which = 0) or V (which = 1) tile that starts at key0, into ring slot `slot` of that operand.
+  // Round 3: a lone wave per SIMD pays for every LDS-DMA piece with its own issue time, so the piece is as cheap as the ISA allows (the
+  // lesson of the one-wave-per-SIMD GEMM, gemm.hip): SCALAR tile base + the lane's fixed 32-bit byte offset (no 64-bit vector add per
+  // piece), M0 written and not saved / restored (nothing else in the kernel uses it).
+  const unsigned lds0_u = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   auto stage_piece = [&](int which, int slot, int key0, int i) {
-    const unsigned short* src = (which ? vbase : kbase) + (int64_t)key0 * ld;
+    const char* sbase = (const char*)((which ? vbase : kbase) + (int64_t)key0 * ld);
     const int piece = wave + C::WAVES * i;
-    // tail keys (key0 + row >= T) re-read the last valid row; they are masked to -inf in the softmax
-    const int row = (key0 + st_row[i] < T) ? st_row[i] : T - 1 - key0;
-    const int off = (key0 + C::KV <= T) ? st_off[i] : row * (int)ld + st_src[i];
-    glds16(src + off, lds_addr(smem) + (which ? C::V_BASE : 0) + slot * C::TILE_BYTES + piece * 1024);
+    unsigned voff = (unsigned)st_off[i] * 2u;
+    if (key0 + C::KV > T) {   // wave-uniform: tail keys (key0 + row >= T) re-read the last valid row; they are masked to -inf in the softmax
+      const int row = (key0 + st_row[i] < T) ? st_row[i] : T - 1 - key0;
+      voff = (unsigned)(row * (int)ld + st_src[i]) * 2u;
+    }
+    const unsigned dst = lds0_u + (which ? C::V_BASE : 0) + slot * C::TILE_BYTES + piece * 1024;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(voff), "s"(sbase) : "memory");
   };
   auto stage = [&](int which, int slot, int key0) {
 #pragma unroll
