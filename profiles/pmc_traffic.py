@@ -8,7 +8,7 @@ import json
 import re
 import sys
 
-ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head"]
+ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head", "attention"]
 
 
 def per_kernel(path, counter):
@@ -29,7 +29,7 @@ fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    m = re.search(r"gemm_nt_\d+x\d+x64<(\d), (\d+)(?:, \d+)?>", k)
+    m = re.search(r"gemm_nt_\w+<(\d), (\d+)(?:, \d+)*>", k)   # every tile kernel: 256x256x64<bf, role, tn, nb>, 4w256 / ring128 / 128x128x64<bf, role>
     if m:
         role = int(m.group(2))
         name = ROLES[role] if role < len(ROLES) else "ext_epilogue"
