@@ -845,11 +845,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_4w256(const tribe_gemm_desc g,
   unsigned dst_cur = lds0 + wave * 8192, dst_nxt = dst_cur + 65536;   // this wave's piece area in the buffer of K-tile t / t+1
 
   f32x4_t acc[8][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
   const int frow = lane & 15, fq = lane >> 4;
   const unsigned coff0 = ((fq ^ (frow & 7)) << 4);
   // fragment read addresses of the current / next buffer, k-step 0 / 1 (fragment i at + i * 2048, an immediate)
@@ -881,19 +876,30 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_4w256(const tribe_gemm_desc g,
   };
 
   // ---- prologue: K-tile 0 landed, its k-step 0 in fragment set 0; K-tile 1 in flight ----
+  // Both K-tiles are requested back to back (their cold-miss latencies overlap; requested one after the other's landing, K-tile 1 stalled
+  // the first landed barrier: ~11 000 cycles of prologue per tile in the stamps of profiles/r03_u_4w_lab.txt); the accumulators are
+  // zeroed while the loads fly.
   {
     const char* a0p = abase + kbytes(0);
     const char* b0p = bbase + kbytes(0);
     static_for<16>([&](auto pc) { dma(pc, dst_cur, a0p, b0p); });
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  static_for<16>([&](auto r) { rd(r, 0, ca0, cb0); });
   if (nk > 1) {
     const char* a1p = abase + kbytes(1);
     const char* b1p = bbase + kbytes(1);
     static_for<16>([&](auto pc) { dma(pc, dst_nxt, a1p, b1p); });
   }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+a"(acc[i][j]));   // (pins the zeroing HERE, under the loads' flight, instead of after the wait)
+    }
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // K-tile 0 landed; the 16 youngest requests are K-tile 1's
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  static_for<16>([&](auto r) { rd(r, 0, ca0, cb0); });
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");   // (the nop: compiler-written accumulator zeros -> first asm MFMA)
   __builtin_amdgcn_sched_barrier(0);
 
