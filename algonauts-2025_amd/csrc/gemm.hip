@@ -174,7 +174,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const int frow = lane & 15, fq = lane >> 4;
   const int coff0 = ((fq ^ (frow & 7)) << 4), coff1 = (((4 + fq) ^ (frow & 7)) << 4);
   const int a_rd = (wr * 128 + frow) * 128;            // + mh*8192 + i*2048 + coff
-  const int b_rd = A_BYTES + (wc * WN + frow) * 128;   // + j*2048 + coff
+  // NT form (TACC): the MFMAs run with their operands SWAPPED and the B fragments are read with their row quads permuted (0, 2, 1, 3), so that
+  // every 16 x 16 accumulator holds its sub-tile transposed with lanes l / l + 32 on adjacent column quads -- what epilogue_fast<.., TACC = 1>
+  // stores without a quad transpose and, for bf16 outputs, 16 bytes per lane.  The transposed-operand (TN) form keeps the
+  // round-2 orientation.
+  constexpr int TACC = TN ? 0 : 1;
+  const int prow = TACC ? ((frow & 3) | ((frow & 4) << 1) | ((frow & 8) >> 1)) : frow;
+  const int bcoff0 = ((fq ^ (prow & 7)) << 4), bcoff1 = (((4 + fq) ^ (prow & 7)) << 4);
+  const int b_rd = A_BYTES + (wc * WN + prow) * 128;   // + j*2048 + bcoff
 
   bf16x8_t fa[4][2], fb[NB][2];
 #ifdef TRIBE_ABL_NO_LDSREAD
@@ -226,8 +233,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
       fb[j][0] = tr_frag((base) + (j >> 1) * 16384 + tb_off[j & 1]);                           \
       fb[j][1] = tr_frag((base) + (j >> 1) * 16384 + tb_off[j & 1] + 32 * 256);                \
     } else {                                                                                   \
-      fb[j][0] = *(const bf16x8_t*)((base) + b_rd + j * 2048 + coff0);                         \
-      fb[j][1] = *(const bf16x8_t*)((base) + b_rd + j * 2048 + coff1);                         \
+      fb[j][0] = *(const bf16x8_t*)((base) + b_rd + j * 2048 + bcoff0);                        \
+      fb[j][1] = *(const bf16x8_t*)((base) + b_rd + j * 2048 + bcoff1);                        \
     }                                                                                          \
   }
 #endif
@@ -239,8 +246,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
 #define TRIBE_MMA(MH)                                                                          \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
   _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                             \
-    acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[j][0], acc[(MH) * 4 + i][j], 0, 0, 0); \
-    acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[j][1], acc[(MH) * 4 + i][j], 0, 0, 0); \
+    acc[(MH) * 4 + i][j] = TACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[(MH) * 4 + i][j], 0, 0, 0)   \
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[j][0], acc[(MH) * 4 + i][j], 0, 0, 0);  \
+    acc[(MH) * 4 + i][j] = TACC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][1], fa[i][1], acc[(MH) * 4 + i][j], 0, 0, 0)   \
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[j][1], acc[(MH) * 4 + i][j], 0, 0, 0);  \
   }
 #endif
 // Priority: ONE s_setprio 1 for the younger wave group (wr = 1, the arbitration loser on every slot) before the K loop instead of
@@ -353,12 +362,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
   if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
     // nothing inside the sub-tile loop waits on memory (gemm_common.h); the staging buffers are idle by now
-    epilogue_fast<OUT_BF16, 8, NB, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 128, n0 + wc * WN, lane, smem + wave * (4 * NB * 1024));
+    epilogue_fast<OUT_BF16, 8, NB, (ROLE == TRIBE_ROLE_EXT), TACC>(g, ctx, acc, m0 + wr * 128, n0 + wc * WN, lane, smem + wave * (4 * NB * 1024));
     return;
   }
   static_for<8 * NB>([&](auto t) {
     constexpr int i = decltype(t)::value / NB, j = decltype(t)::value % NB;
-    epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * WN + j * 16, lane);
+    epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT), TACC>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * WN + j * 16, lane);
   });
 }
 

@@ -303,13 +303,21 @@ __device__ __forceinline__ void static_for(F&& f) {
 // with a residual, and tiles that cross N take the generic path.
 // NI x NJ = the wave's accumulator grid of 16 x 16 sub-tiles; a round covers RI = min(NI, 4) sub-tile rows x NJ columns (<= 16 sub-tiles,
 // 1 KiB of LDS each for the tile-shaped addend).  Row sums of squares go to slot nw / (16 NJ): one slot per wave column group.
-template <int OUT_BF16, int NI, int NJ, int EXT>
+// TACC = 1 (round 3; the 8-wave 256-row kernel, NT form): the K loop multiplied with the MFMA operands SWAPPED and the B fragment row quads
+// permuted (0, 2, 1, 3), so a 16 x 16 accumulator holds its sub-tile transposed: register r of lane l is C[row l & 15][column 4 sigma(l >> 4) + r].
+// A lane then owns four consecutive columns of one row WITHOUT the quad transpose (16 vector instructions per sub-tile), lanes l and l + 32
+// own adjacent column quads, and bf16 outputs are written 16 bytes per lane: two v_permlane32_swap per PAIR of sub-tiles (j, j + 1) give the
+// lower half-wave 8 consecutive columns of sub-tile j and the upper half those of j + 1 -- half the store instructions (an epilogue's
+// stores cost a wave ~400 cycles each whatever their width).
+template <int OUT_BF16, int NI, int NJ, int EXT, int TACC = 0>
 __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t (&acc)[NI][NJ], int64_t mw, int64_t nw, int lane,
                                               char* lds_wave) {
   constexpr int RI = NI >= 4 ? 4 : NI;
   static_assert(NI % RI == 0 && NJ >= 1 && NJ <= 4, "accumulator grid");
-  const int64_t row0 = mw + ((lane >> 4) << 2) + (lane & 3);      // + 16 i
-  const int64_t col0 = nw + (((lane & 15) >> 2) << 2);            // + 16 j
+  const int tq = lane >> 4;
+  const int64_t row0 = TACC ? mw + (lane & 15) : mw + ((lane >> 4) << 2) + (lane & 3);                       // + 16 i
+  const int64_t col0 = TACC ? nw + 4 * ((tq & 1) * 2 + (tq >> 1)) : nw + (((lane & 15) >> 2) << 2);          // + 16 j
+  const int64_t colp = nw + 16 * (lane >> 5) + 8 * (tq & 1);   // TACC: first of the 8 columns a paired bf16 store writes (+ 16 j, j even)
   const bool bias_col = g.bias_mode == TRIBE_BIAS_COL, bias_row = g.bias_mode == TRIBE_BIAS_ROW;
   const bool res_scaled = c.res && g.res_scale;
   const bool pair_act = EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU);
@@ -363,12 +371,19 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
         pre[EXT ? s : 0] = r < g.M ? *(const u16x4_t*)((const unsigned short*)g.aux + c.c_off + r * g.ld_aux + col0 + j * 16) : u16x4_t{0, 0, 0, 0};
       });
     }
+    uint2 pend = make_uint2(0u, 0u);   // TACC: the packed bf16 quad of a pair's first sub-tile
     static_for<RI * NJ>([&](auto st) {
       constexpr int s = decltype(st)::value, i4 = s / NJ, i = round * RI + i4, j = s % NJ;
       const int64_t row = row0 + i * 16;
       float v[4];
-      quad_transpose(acc[i][j], g.alpha, lane, v);   // all four lanes of a quad take part, including those whose row is past M
-      if (row >= g.M) return;
+      if constexpr (TACC) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k] * g.alpha;
+      } else {
+        quad_transpose(acc[i][j], g.alpha, lane, v);   // all four lanes of a quad take part, including those whose row is past M
+      }
+      const bool live = row < g.M;
+      if (!TACC && !live) return;   // (TACC: every lane stays for the half-wave exchanges of the paired stores; loads and stores are guarded)
       if (g.row_scale) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] *= srow[i4];
@@ -384,8 +399,10 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
         const float o0 = glu ? v[0] * sigmoid_f(v[1]) : silu_f(v[0]) * v[1];
         const float o1 = glu ? v[2] * sigmoid_f(v[3]) : silu_f(v[2]) * v[3];
         const int64_t oidx = c.c_off + row * g.ldc + ((col0 + j * 16) >> 1);
-        if (OUT_BF16) *(unsigned int*)((unsigned short*)c.C + oidx) = (unsigned int)f32_to_bf16(o0) | ((unsigned int)f32_to_bf16(o1) << 16);
-        else *(float2*)((float*)c.C + oidx) = make_float2(o0, o1);
+        if (live) {
+          if (OUT_BF16) *(unsigned int*)((unsigned short*)c.C + oidx) = (unsigned int)f32_to_bf16(o0) | ((unsigned int)f32_to_bf16(o1) << 16);
+          else *(float2*)((float*)c.C + oidx) = make_float2(o0, o1);
+        }
         return;
       }
       if (g.act == TRIBE_ACT_GELU) {
@@ -393,7 +410,7 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
           u16x4_t p;
 #pragma unroll
           for (int k = 0; k < 4; ++k) p[k] = f32_to_bf16(v[k]);
-          *(u16x4_t*)((unsigned short*)g.aux + c.c_off + row * g.ld_aux + col0 + j * 16) = p;
+          if (live) *(u16x4_t*)((unsigned short*)g.aux + c.c_off + row * g.ld_aux + col0 + j * 16) = p;
         }
         if (OUT_BF16) {
           const f32x2_t lo = gelu_poly2(f32x2_t{v[0], v[1]}), hi = gelu_poly2(f32x2_t{v[2], v[3]});
@@ -414,20 +431,31 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
         else { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
       }
       const int64_t idx = c.c_off + row * g.ldc + col0 + j * 16;
-      if (OUT_BF16) {
+      // a bf16 row of 4 values: alone (8 bytes), or -- TACC, sub-tiles in pairs -- merged with the partner half-wave's into 16 bytes
+      auto store_bf16 = [&](unsigned short* base, int64_t ld, int64_t boff) {
         u16x4_t o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
-        *(u16x4_t*)((unsigned short*)c.C + idx) = o;
-      } else {
-        *(float4*)((float*)c.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
-        if (g.c_bf16) {   // the next GEMM's A operand, un-normalised (its ScaleNorm factor rides in that GEMM's row_scale)
-          u16x4_t o;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
-          *(u16x4_t*)(g.c_bf16 + row * g.ld_c_bf16 + col0 + j * 16) = o;
+        constexpr bool paired = TACC && (NJ % 2 == 0 || j + 1 < NJ || (j & 1));
+        if constexpr (!paired) {
+          if (live) *(u16x4_t*)(base + boff + row * ld + col0 + j * 16) = o;
+        } else {
+          const uint2 pk = __builtin_bit_cast(uint2, o);
+          if constexpr ((j & 1) == 0) {
+            pend = pk;
+          } else {
+            const auto sx = __builtin_amdgcn_permlane32_swap(pend.x, pk.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pend.y, pk.y, false, false);
+            if (live) *(uint4*)(base + boff + row * ld + colp + (j - 1) * 16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          }
         }
-        if (g.row_sumsq) ssq[i4] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      };
+      if (OUT_BF16) {
+        store_bf16((unsigned short*)c.C, g.ldc, c.c_off);
+      } else {
+        if (live) *(float4*)((float*)c.C + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.c_bf16) store_bf16(g.c_bf16, g.ld_c_bf16, 0);   // the next GEMM's A operand, un-normalised (its ScaleNorm factor rides in that GEMM's row_scale)
+        if (g.row_sumsq && live) ssq[i4] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
       }
     });
     if (!OUT_BF16 && g.row_sumsq) {
@@ -435,10 +463,10 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
       static_for<RI>([&](auto it) {
         constexpr int i4 = decltype(it)::value;
         float t = ssq[i4];
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, TACC ? 16 : 4, 64);   // the four lanes that share a row
+        t += __shfl_xor(t, TACC ? 32 : 8, 64);
         const int64_t r = row0 + (round * RI + i4) * 16;
-        if ((lane & 12) == 0 && r < g.M) g.row_sumsq[r * g.ld_row_sumsq + (int64_t)((unsigned)nw / (unsigned)(16 * NJ))] = t;
+        if ((TACC ? lane < 16 : (lane & 12) == 0) && r < g.M) g.row_sumsq[r * g.ld_row_sumsq + (int64_t)((unsigned)nw / (unsigned)(16 * NJ))] = t;
       });
     }
   });
@@ -455,10 +483,17 @@ __device__ __forceinline__ bool epilogue_fast_ok(const tribe_gemm_desc& g, const
 }
 
 // One 16x16 accumulator tile -> epi(...) -> C, straight from registers (one 16-/8-byte store per lane).
-template <int OUT_BF16, int EXT>
+template <int OUT_BF16, int EXT, int TACC = 0>
 __device__ __forceinline__ void epilogue_tile16(const tribe_gemm_desc& g, const EpiCtx& c, f32x4_t acc, int64_t mt0,
                                                 int64_t nt0, int lane) {
   float v[4];
-  quad_transpose(acc, g.alpha, lane, v);
-  epilogue_row4<OUT_BF16, EXT>(g, c, v, mt0 + ((lane >> 4) << 2) + (lane & 3), nt0 + (((lane & 15) >> 2) << 2));
+  if constexpr (TACC) {   // transposed accumulation (see epilogue_fast): four consecutive columns of one row per lane as they are
+    const int tq = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = acc[k] * g.alpha;
+    epilogue_row4<OUT_BF16, EXT>(g, c, v, mt0 + (lane & 15), nt0 + 4 * ((tq & 1) * 2 + (tq >> 1)));
+  } else {
+    quad_transpose(acc, g.alpha, lane, v);
+    epilogue_row4<OUT_BF16, EXT>(g, c, v, mt0 + ((lane >> 4) << 2) + (lane & 3), nt0 + (((lane & 15) >> 2) << 2));
+  }
 }
