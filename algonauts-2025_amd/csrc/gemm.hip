@@ -178,7 +178,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   // every 16 x 16 accumulator holds its sub-tile transposed with lanes l / l + 32 on adjacent column quads -- what epilogue_fast<.., TACC = 1>
   // stores without a quad transpose and, for bf16 outputs, 16 bytes per lane.  The transposed-operand (TN) form keeps the
   // round-2 orientation.
+#ifdef TRIBE_GEMM_NO_TACC
+  constexpr int TACC = 0;
+#else
   constexpr int TACC = TN ? 0 : 1;
+#endif
   const int prow = TACC ? ((frow & 3) | ((frow & 4) << 1) | ((frow & 8) >> 1)) : frow;
   const int bcoff0 = ((fq ^ (prow & 7)) << 4), bcoff1 = (((4 + fq) ^ (prow & 7)) << 4);
   const int b_rd = A_BYTES + (wc * WN + prow) * 128;   // + j*2048 + bcoff
@@ -1164,7 +1168,7 @@ extern "C" int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64
 
 
 #ifndef TRIBE_GEMM_4W_DEFAULT
-#define TRIBE_GEMM_4W_DEFAULT 1
+#define TRIBE_GEMM_4W_DEFAULT 0   // see gemm_plan: after the 8-wave kernel took over its epilogue techniques the two tie; tile_hint 5 selects it
 #endif
 namespace tribe_gemm_detail {
 // Which kernel and tile a launch gets.  sumsq_cols = columns per row_sumsq slot (one slot per wave column group).
@@ -1225,9 +1229,11 @@ static GemmPlan gemm_plan(const tribe_gemm_desc* d) {
   if (fused_norm && d->N % bn != 0) bn = (d->N % 256 == 0) ? 256 : 192;
   // 256 x 256 tiles of the four encoder GEMMs: the one-wave-per-SIMD kernel, whose epilogue is compiled for exactly their operator sets
   // (tile_hint 2 keeps the 8-wave form for A/B runs; everything else -- other roles, batched, transposed operands -- stays 8-wave)
-  // Default: QKV and FF1 (bf16 outputs: +4.1 % / +3.2 % over the 8-wave kernel with their model epilogues at B = 64, +3 ... 4 % at B = 4,
-  // profiles/r03_u_4w_lab.txt); the residual-stream GEMMs (out-proj, FF2) keep the 8-wave kernel, whose two waves per SIMD overlap the
-  // 640 KiB of epilogue traffic per tile better (-1 ... -3 % for the 4-wave form there); tile_hint 5 forces the 4-wave kernel for all four.
+  // The one-wave-per-SIMD kernel (tile_hint 5; QKV / FF1 / out-proj / FF2 with their model epilogues).  History of the default: with the round-2
+  // epilogue in the 8-wave kernel it won QKV / FF1 by 4.4 / 4.5 % (profiles/r03_z1_4w_lab.txt); its epilogue techniques (transposed accumulation,
+  // paired 16-byte bf16 stores) then went into the 8-wave kernel (TACC), after which the two tie in isolation (profiles/r03_z2_4w_lab.txt) and in the
+  // whole step (same box, bench.py: 8-wave only 639.7 - 640.4 k TRs/s, 4-wave for QKV / FF1 637.2 - 638.2 k: the step runs at the chip's power
+  // limit, a kernel that draws less lets its neighbours clock higher and vice versa).  Default: 8-wave everywhere.
   const bool w4_default = TRIBE_GEMM_4W_DEFAULT && d->tile_hint == 0 && (d->role == TRIBE_ROLE_QKV || d->role == TRIBE_ROLE_FF1);
   if (bn == 256 && (d->tile_hint == 5 || w4_default) && w4_role_ok(d)) return {KIND_BIG4W, 256, 256, 64};
   return {KIND_BIG, 256, bn, bn / 4};
