@@ -609,8 +609,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wide384_kernel(const AttnArgs
 
   // ---- normalise and write: O^T[d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h][q = r31] -> out[q][hd * DH + d] ----
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-  const float inv = 1.0f / pair_sum(l_run);
+  const float l_tot = pair_sum(l_run);
+  const float inv = 1.0f / l_tot;
   const int q = q0 + r31;
+  // what a backward pass needs to rebuild P = exp2(s * scale * log2 e - lse2) without a softmax (TRIBE_ACT_EXP2): one float per query
+  if (a.lse != nullptr && h == 0 && q < T) a.lse[((int64_t)b * a.heads_q + hd) * T + q] = m_run + __builtin_amdgcn_logf(l_tot);
   unsigned short* orow = a.out + ((int64_t)b * T + (q < T ? q : T - 1)) * a.ld_out + (int64_t)hd * C::DH + 4 * h;
   static_for<0, C::DT>([&](auto dtc) {
     constexpr int dt = decltype(dtc)::value;
@@ -1002,6 +1005,9 @@ static int attention_dispatch_impl(const tribe_attention_desc* d, const float* q
   a.n_bh = (int)(d->B * d->heads_q);
   a.qe = d->rel_qe; a.ld_qe = d->ld_rel_qe; a.qe_stride_h = d->rel_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
   a.q_cos = q_cos; a.q_sin = q_sin; a.q_rot_dim = q_rot_dim;
+  a.lse = d->lse;
+  TRIBE_REQUIRE(!d->lse || (tribe_attention_lse_supported(d->dim_head, d->causal) && !d->rel_qe),
+                "tribe_attention_fwd_ex: the log-sum-exp output exists for dim_head 384, bidirectional, default mode only");
   hipStream_t s = (hipStream_t)stream;
 #ifdef TRIBE_ATTN_STAMPS
   if (d->rel_qe && d->dim_head == 384) return launch_attn_dh<384>(a, d->B, d->causal, s);   // rel_qe carries the stamp buffer
@@ -1025,6 +1031,8 @@ static int attention_dispatch_impl(const tribe_attention_desc* d, const float* q
 extern "C" int tribe_attention_fwd_ex(const tribe_attention_desc* d, void* stream) { return attention_dispatch(d, nullptr, nullptr, 0, stream); }
 
 // 1 when the next fused launch at this head size rotates Q itself if given the tables (the DH = 384 one-wave kernel)
+extern "C" int tribe_attention_lse_supported(int32_t dim_head, int32_t causal) { return dim_head == 384 && !causal && g_attn_wide384 == 1; }
+
 int tribe_internal_attention_rotates_q(int dim_head) { return dim_head == 384 && g_attn_wide384 == 1; }
 
 static tribe_attention_desc fused_desc(const uint16_t* qkv, int64_t B, int64_t T, int heads, int dim_head, float scale, uint16_t* out) {
@@ -1035,6 +1043,7 @@ static tribe_attention_desc fused_desc(const uint16_t* qkv, int64_t B, int64_t T
   d.out = out; d.ld_out = inner;
   d.B = B; d.T = T; d.heads_q = heads; d.heads_kv = heads; d.dim_head = dim_head; d.causal = 0; d.scale = scale;
   d.rel_qe = nullptr; d.ld_rel_qe = 0; d.rel_stride_h = 0; d.rel_left = d.rel_right = 0;
+  d.lse = nullptr;
   return d;
 }
 

@@ -44,6 +44,7 @@ struct AttnArgs {
   // partial rotary of Q applied while the Q fragments are loaded (DH = 384 one-wave kernel only): interleaved pairs (2 i, 2 i + 1),
   // tables f32 [T, rot_dim / 2]; nullptr = q arrives rotated.  Same arithmetic, same bf16 rounding as rotary_kernel.
   const float* q_cos; const float* q_sin; int q_rot_dim;
+  float* lse;   // optional [B, heads_q, T] base-2 log-sum-exp of the scaled scores (DH = 384 one-wave kernel only; nullptr = not wanted)
 };
 
 // compile-time loop: the accumulator tile index selects literal registers (attn_acc_regs.h)

@@ -686,6 +686,47 @@ extern "C" int tribe_softmax_bwd(const uint16_t* P, const float* dP, int64_t row
   return 0;
 }
 
+// D[b][h][t] = scale * sum_d a[b T + t][h dh + d] * b[b T + t][h dh + d]: one wave per (row, head), 8 bf16 (16 bytes) per lane and operand.
+// The rowsum(dO * O) of the attention backward (= rowsum(P * dP), FlashAttention-2 eq. for D), written as the row bias the dS GEMM adds.
+__global__ __launch_bounds__(256) void rowdot_heads_kernel(const unsigned short* __restrict__ a, int64_t ld_a, const unsigned short* __restrict__ b,
+                                                           int64_t ld_b, int64_t rows, int T, int heads, int dim_head, float scale,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (row, head), head fastest
+  if (item >= rows * heads) return;
+  const int64_t row = item / heads;
+  const int hd = (int)(item - row * heads);
+  const unsigned short* pa = a + row * ld_a + (int64_t)hd * dim_head;
+  const unsigned short* pb = b + row * ld_b + (int64_t)hd * dim_head;
+  float acc = 0.f;
+  for (int d = lane * 8; d < dim_head; d += 512) {
+    const uint4 va = *(const uint4*)(pa + d), vb = *(const uint4*)(pb + d);
+    const unsigned int wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc = fmaf(__uint_as_float(wa[k] << 16), __uint_as_float(wb[k] << 16), acc);
+      acc = fmaf(__uint_as_float(wa[k] & 0xffff0000u), __uint_as_float(wb[k] & 0xffff0000u), acc);
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[((row / T) * heads + hd) * (int64_t)T + row % T] = acc * scale;
+}
+
+extern "C" int tribe_rowdot_heads_bf16(const uint16_t* a, int64_t ld_a, const uint16_t* b, int64_t ld_b, int64_t B, int64_t T, int32_t heads,
+                                       int32_t dim_head, float scale, float* out, void* stream) {
+  TRIBE_REQUIRE(a && b && out, "tribe_rowdot_heads_bf16: null pointer");
+  TRIBE_REQUIRE(B > 0 && T > 0 && T < (1ll << 31) && heads > 0 && dim_head > 0 && dim_head % 8 == 0, "tribe_rowdot_heads_bf16: bad shape");
+  TRIBE_REQUIRE(ld_a >= (int64_t)heads * dim_head && ld_b >= (int64_t)heads * dim_head && ld_a % 8 == 0 && ld_b % 8 == 0 &&
+                    ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0,
+                "tribe_rowdot_heads_bf16: rows must be 16-byte aligned and at least heads * dim_head wide");
+  const int64_t items = B * T * heads;
+  TRIBE_REQUIRE((items + 3) / 4 < (1ll << 31), "tribe_rowdot_heads_bf16: grid too large");
+  hipLaunchKernelGGL(rowdot_heads_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, ld_a, b, ld_b, B * T, (int)T,
+                     (int)heads, (int)dim_head, scale, out);
+  TRIBE_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int tribe_softmax_fwd(const float* S, int64_t rows, int64_t T, int64_t ld_s, uint16_t* P, int64_t T_pad, int64_t ld_p, void* stream) {
   TRIBE_REQUIRE(S && P, "tribe_softmax_fwd: null pointer");
   TRIBE_REQUIRE(rows > 0 && T > 0 && T_pad >= T && ld_s >= T && ld_p >= T_pad, "tribe_softmax_fwd: bad shape");

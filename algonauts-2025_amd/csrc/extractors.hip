@@ -149,7 +149,7 @@ extern "C" int tribe_llama_fwd(const tribe_llama_desc* d, float* states, void* w
     a.B = d->B; a.T = d->T; a.heads_q = d->heads_q; a.heads_kv = d->heads_kv; a.dim_head = d->dim_head;
     a.causal = 1;  // right padding + causal mask: real tokens never see pad keys, pad rows are never pooled
     a.scale = 1.0f / sqrtf((float)d->dim_head);
-    a.rel_qe = nullptr; a.ld_rel_qe = 0; a.rel_stride_h = 0; a.rel_left = a.rel_right = 0;
+    a.rel_qe = nullptr; a.ld_rel_qe = 0; a.rel_stride_h = 0; a.rel_left = a.rel_right = 0; a.lse = nullptr;
     rc = tribe_attention_fwd_ex(&a, stream);
     if (rc) return rc;
     g = gemm_zero();
@@ -276,7 +276,7 @@ extern "C" int tribe_vjepa2_fwd(const tribe_vjepa2_desc* d, float* states, void*
     a.out = ao; a.ld_out = dim;
     a.B = d->B; a.T = p.tokens; a.heads_q = d->heads; a.heads_kv = d->heads; a.dim_head = d->dim_head; a.causal = 0;
     a.scale = 1.0f / sqrtf((float)d->dim_head);
-    a.rel_qe = nullptr; a.ld_rel_qe = 0; a.rel_stride_h = 0; a.rel_left = a.rel_right = 0;
+    a.rel_qe = nullptr; a.ld_rel_qe = 0; a.rel_stride_h = 0; a.rel_left = a.rel_right = 0; a.lse = nullptr;
     rc = tribe_attention_fwd_ex(&a, stream);
     if (rc) return rc;
     g = gemm_zero();
@@ -444,7 +444,7 @@ extern "C" int tribe_w2vbert_fwd(const tribe_w2vbert_desc* d, float* states, voi
     a.out = ao; a.ld_out = dim;
     a.B = d->B; a.T = d->T; a.heads_q = d->heads; a.heads_kv = d->heads; a.dim_head = d->dim_head; a.causal = 0;
     a.scale = 1.0f / sqrtf((float)d->dim_head);
-    a.rel_qe = qe; a.ld_rel_qe = p.qe_ld; a.rel_stride_h = qe_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right;
+    a.rel_qe = qe; a.ld_rel_qe = p.qe_ld; a.rel_stride_h = qe_stride_h; a.rel_left = d->rel_left; a.rel_right = d->rel_right; a.lse = nullptr;
     rc = tribe_attention_fwd_ex(&a, stream);
     if (rc) return rc;
     g = gemm_zero();

@@ -1261,7 +1261,13 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(!d->gadd || (d->gadd_index && d->gadd_div > 0), "tribe_gemm_bf16: gadd needs index and divisor");
   TRIBE_REQUIRE(!(d->gather_a || d->gather_bias || d->gather_b) || d->gather1, "tribe_gemm_bf16: gather flags set without gather1");
   TRIBE_REQUIRE(d->act != TRIBE_ACT_GELU_BWD || d->aux, "tribe_gemm_bf16: GELU_BWD needs the saved pre-activation in aux");
-  TRIBE_REQUIRE(!d->aux || (d->ld_aux >= d->N && d->batch1 * d->batch0 == 1), "tribe_gemm_bf16: aux is supported for un-batched GEMMs");
+  TRIBE_REQUIRE(d->act != TRIBE_ACT_MUL_AUX || (d->aux && d->ld_aux == d->ldc), "tribe_gemm_bf16: MUL_AUX needs aux laid out like C (ld_aux == ldc)");
+  TRIBE_REQUIRE((d->act != TRIBE_ACT_EXP2 && d->act != TRIBE_ACT_MUL_AUX) || (!d->res && !d->rowadd && !d->gadd && d->bias_mode != TRIBE_BIAS_COL),
+                "tribe_gemm_bf16: EXP2 / MUL_AUX take a row bias only");
+  // (aux is addressed with C's batch offsets: the GELU pre-activation is un-batched, MUL_AUX's factor shares C's layout)
+  TRIBE_REQUIRE(!d->aux || (d->ld_aux >= d->N && (d->batch1 * d->batch0 == 1 || d->act == TRIBE_ACT_MUL_AUX)),
+                "tribe_gemm_bf16: aux is supported for un-batched GEMMs (and for MUL_AUX)");
+  TRIBE_REQUIRE(d->sBias0 == 0 || d->bias_mode == TRIBE_BIAS_ROW, "tribe_gemm_bf16: sBias0 belongs to a row bias");
   const int64_t nz = d->batch1 * d->batch0;
   if (d->c_bf16 || d->row_sumsq || d->row_scale) {
     // fused ScaleNorm operands exist only in the wait-free epilogue: insist on everything that path needs
@@ -1284,7 +1290,7 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
     TRIBE_REQUIRE(d->M >= 8 && d->N >= 8 && d->M % 8 == 0 && d->N % 8 == 0 && d->lda >= d->M && d->ldb >= d->N,
                   "tribe_gemm_bf16: trans_ab takes At [K, M] and Bt [K, N] with M and N multiples of 8 and lda >= M, ldb >= N");
     TRIBE_REQUIRE(!d->aux && d->act != TRIBE_ACT_SWIGLU && d->act != TRIBE_ACT_GLU && d->act != TRIBE_ACT_SILU && d->act != TRIBE_ACT_GELU_BWD &&
-                      !d->gather_a && !d->gather_b,
+                      d->act != TRIBE_ACT_EXP2 && d->act != TRIBE_ACT_MUL_AUX && !d->gather_a && !d->gather_b,
                   "tribe_gemm_bf16: trans_ab supports the plain epilogue operators and no operand gather");
   }
   const int64_t tiles_m = (d->M + plan.bm - 1) / plan.bm, tiles_n = (d->N + plan.bn - 1) / plan.bn;
@@ -1303,7 +1309,7 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
     return 0;
   }
   const bool ext = d->aux != nullptr || d->act == TRIBE_ACT_SWIGLU || d->act == TRIBE_ACT_GLU || d->act == TRIBE_ACT_SILU ||
-                   d->act == TRIBE_ACT_GELU_BWD;
+                   d->act == TRIBE_ACT_GELU_BWD || d->act == TRIBE_ACT_EXP2 || d->act == TRIBE_ACT_MUL_AUX;
   int pair = bf ? 0 : 1;   // GENERIC
   if (ext) {
     pair = bf ? 2 : 3;

@@ -124,7 +124,7 @@ struct EpiCtx {
 __device__ __forceinline__ EpiCtx make_epi_ctx(const tribe_gemm_desc& g, int64_t b1, int64_t b0, int64_t b1g) {
   EpiCtx c;
   const int64_t bb = g.gather_bias ? b1g : b1;
-  c.bias = g.bias ? g.bias + bb * g.sBias1 : nullptr;
+  c.bias = g.bias ? g.bias + bb * g.sBias1 + b0 * g.sBias0 : nullptr;
   c.res = g.res ? g.res + b1 * g.sRes1 + b0 * g.sRes0 : nullptr;
   c.C = (char*)g.C;
   c.c_off = b1 * g.sC1 + b0 * g.sC0;
@@ -213,6 +213,13 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
     } else if (EXT && g.act == TRIBE_ACT_SILU) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+    } else if (EXT && g.act == TRIBE_ACT_EXP2) {   // attention backward: P = exp2(scaled score - lse2[row]) (the row bias)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_exp2f(v[k]);
+    } else if (EXT && g.act == TRIBE_ACT_MUL_AUX) {   // attention backward: dS = (scale dP - scale D[row]) * P
+      const u16x4_t p = *(const u16x4_t*)((const unsigned short*)g.aux + c.c_off + m * g.ld_aux + n);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= bf16_to_f32(p[k]);
     }
     if (c.res) {
       const float4 r = *(const float4*)(c.res + m * g.ldres + n);
@@ -265,6 +272,8 @@ __device__ __forceinline__ void epilogue_row4(const tribe_gemm_desc& g, const Ep
     } else if (EXT && g.act == TRIBE_ACT_GELU_BWD) {
       x *= gelu_grad(bf16_to_f32(((const unsigned short*)g.aux)[c.c_off + m * g.ld_aux + n + k]));
     } else if (EXT && g.act == TRIBE_ACT_SILU) x = silu_f(x);
+    else if (EXT && g.act == TRIBE_ACT_EXP2) x = __builtin_amdgcn_exp2f(x);
+    else if (EXT && g.act == TRIBE_ACT_MUL_AUX) x *= bf16_to_f32(((const unsigned short*)g.aux)[c.c_off + m * g.ld_aux + n + k]);
     if (c.res) {
       const float r = c.res[m * g.ldres + n + k];
       x += g.res_scale ? r * g.res_scale[n + k] : r;
@@ -363,8 +372,8 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
     }
     // training dgrad through GELU: the saved bf16 pre-activations of the round, fetched together (32 VGPRs, EXT kernels only)
     u16x4_t pre[EXT ? RI * NJ : 1];
-    const bool gelu_bwd = EXT && g.act == TRIBE_ACT_GELU_BWD;
-    if (gelu_bwd) {
+    const bool gelu_bwd = EXT && g.act == TRIBE_ACT_GELU_BWD, mul_aux = EXT && g.act == TRIBE_ACT_MUL_AUX;
+    if (gelu_bwd || mul_aux) {
       static_for<RI * NJ>([&](auto st) {
         constexpr int s = decltype(st)::value, i = round * RI + s / NJ, j = s % NJ;
         const int64_t r = row0 + i * 16;
@@ -421,9 +430,15 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
         }
       } else if (gelu_bwd) {
         gelu_grad_mul4(v, pre[EXT ? s : 0]);
+      } else if (mul_aux) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= bf16_to_f32(pre[EXT ? s : 0][k]);
       } else if (EXT && g.act == TRIBE_ACT_SILU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+      } else if (EXT && g.act == TRIBE_ACT_EXP2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_exp2f(v[k]);
       }
       if (tile_add) {
         const float4 r = *(const float4*)(lds_wave + s * 1024 + lane * 16);
@@ -477,7 +492,8 @@ __device__ __forceinline__ void epilogue_fast(const tribe_gemm_desc& g, const Ep
 template <int EXT>
 __device__ __forceinline__ bool epilogue_fast_ok(const tribe_gemm_desc& g, const EpiCtx& c) {
   const bool act_ok = g.act == TRIBE_ACT_NONE || g.act == TRIBE_ACT_GELU ||
-                      (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU || g.act == TRIBE_ACT_SILU || g.act == TRIBE_ACT_GELU_BWD));
+                      (EXT && (g.act == TRIBE_ACT_SWIGLU || g.act == TRIBE_ACT_GLU || g.act == TRIBE_ACT_SILU || g.act == TRIBE_ACT_GELU_BWD ||
+                              g.act == TRIBE_ACT_EXP2 || g.act == TRIBE_ACT_MUL_AUX));
   const bool rowadd_ok = !g.rowadd || (!c.res && g.M < (1ll << 31) && g.rowadd_period < (1ll << 31));   // rides in the residual's LDS slot
   return c.vec && rowadd_ok && !g.gadd && (EXT || !g.aux) && act_ok;   // (the launcher refuses the fused-norm operands unless this holds)
 }

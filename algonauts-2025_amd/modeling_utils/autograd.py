@@ -24,13 +24,17 @@ from tribe_hip._lib import BF16, F32, GemmDesc, check, lib
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
+_LOG2E = 1.4426950408889634
+
+
 def _s() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
 def _gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, lda=None, ldb=None, ldc=None, M=None, N=None, K=None, alpha=1.0,
           bias=None, act=_lib.ACT_NONE, aux=None, res=None, ldres=None, res_scale=None, batch1=1, batch0=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
-          gather1=None, gather_a=False, gather_b=False, a_off=0, b_off=0, c_off=0, role=0, trans_ab=False) -> None:
+          gather1=None, gather_a=False, gather_b=False, a_off=0, b_off=0, c_off=0, role=0, trans_ab=False, row_bias=None, row_bias_off=0,
+          sBias=(0, 0), ld_aux=None) -> None:
     """Thin positional wrapper over tribe_gemm_bf16 (element offsets allow strided views without copies)."""
     d = GemmDesc()
     d.trans_ab = int(trans_ab)
@@ -41,8 +45,10 @@ def _gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, lda=None, ldb=
     d.c_dtype, d.alpha, d.act, d.role = _DT[out.dtype], alpha, act, role
     if bias is not None:
         d.bias, d.bias_mode = bias.data_ptr(), _lib.BIAS_COL
+    if row_bias is not None:   # f32 per output row, batch strides sBias (elements)
+        d.bias, d.bias_mode, d.sBias1, d.sBias0 = row_bias.data_ptr() + 4 * row_bias_off, _lib.BIAS_ROW, sBias[0], sBias[1]
     if aux is not None:
-        d.aux, d.ld_aux = aux.data_ptr(), N
+        d.aux, d.ld_aux = aux.data_ptr(), (ld_aux if ld_aux is not None else N)
     if res is not None:
         d.res, d.ldres = res.data_ptr() + 4 * c_off, (ldres if ldres is not None else ldc)
         d.sRes1, d.sRes0 = sC
@@ -397,50 +403,85 @@ class Rotary(torch.autograd.Function):
 
 class Attention(torch.autograd.Function):
     """softmax(q k^T * scale) v per (batch, head) on a fused bf16 qkv [B*T, 3*inner]; forward = fused flash kernel,
-    backward = materialised (S, P recomputed per batch chunk; five MFMA GEMM products per head)."""
+    backward = five MFMA GEMM products per head on P / dS recomputed per batch chunk.  Where the forward kernel can hand over its
+    log-sum-exp (dim_head 384) the backward keeps no f32 [B h, T, T] tensor and runs no softmax kernel: the score GEMM's epilogue writes
+    P = exp2(scale log2e q.k - lse2[row]) (ACT_EXP2), the dO V^T GEMM's epilogue writes dS = scale (dP - D[row]) * P (ACT_MUL_AUX) with
+    D = rowsum(dO * O) (FlashAttention-2's identity for rowsum(P * dP)); 12 bytes of HBM traffic per score instead of 28.  Other head
+    sizes (and FUSED_SOFTMAX = False) take the materialised S / dP + softmax kernels."""
 
     # f32 score bytes per chunk of sequences.  Same box, B = 16 (scripts/train_bench.py attn-chunk=N): 7 sequences (256 MiB) 112.0 ms,
     # 4 sequences 110.9, 2 sequences 117.4, 1 sequence 122.5 -- smaller chunks keep more of S / P / dP / dS in the Infinity Cache but
     # leave the batched GEMMs under one round of tiles
     CHUNK_BYTES = 144 << 20
+    # With the fused-softmax backward only P and dS (bf16) exist and fewer, larger batched GEMMs win: B = 16 in one chunk 102.8 ms, 8 sequences
+    # 103.7, 4 sequences 104.5 (materialised path, 4 sequences: 105.8; same box, profiles/r03_z5_train.txt)
+    CHUNK_BYTES_FUSED = 1 << 30
+    FUSED_SOFTMAX = True
+
+    @staticmethod
+    def _fwd(ctx, qkv, B: int, T: int, heads: int, dim_head: int, scale: float):
+        if Attention.FUSED_SOFTMAX and ops.attention_lse_supported(dim_head):
+            out, lse = ops.attention_with_lse(qkv, B, T, heads, dim_head, scale)
+            ctx.save_for_backward(qkv, out, lse)
+        else:
+            out = ops.attention(qkv, B, T, heads, dim_head, scale)
+            ctx.save_for_backward(qkv)
+        return out
 
     @staticmethod
     def forward(ctx, qkv, B: int, T: int, heads: int, dim_head: int, scale: float):
-        out = ops.attention(qkv, B, T, heads, dim_head, scale)
-        ctx.save_for_backward(qkv)
+        out = Attention._fwd(ctx, qkv, B, T, heads, dim_head, scale)
         ctx.meta = (B, T, heads, dim_head, scale)
         ctx.rotary = None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (qkv,) = ctx.saved_tensors
+        qkv = ctx.saved_tensors[0]
+        fused = len(ctx.saved_tensors) == 3
         B, T, h, d, scale = ctx.meta
         inner, ld = h * d, 3 * h * d
         dev = qkv.device
         dout = cast_bf16(dout)
         dqkv = torch.empty_like(qkv)
         Tp = ops.round_up(T, 64)
-        chunk = max(1, min(B, Attention.CHUNK_BYTES // (h * T * Tp * 4)))
-        S = torch.empty(chunk * h, T, Tp, dtype=torch.float32, device=dev)
-        P = torch.empty(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
-        dP = torch.empty(chunk * h, T, Tp, dtype=torch.float32, device=dev)
-        dS = torch.empty(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
+        chunk = max(1, min(B, (Attention.CHUNK_BYTES_FUSED if fused else Attention.CHUNK_BYTES) // (h * T * Tp * 4)))
+        if fused:
+            _, out, lse = ctx.saved_tensors
+            neg_lse = lse.neg()                                             # the row biases of the two epilogues, [B, h, T] f32
+            neg_d = ops.rowdot_heads(dout, out, B, T, h, d, -scale)
+            # (the GEMMs write columns < T only: the pad columns the K = T_pad products read stay zero)
+            P = (torch.zeros if Tp != T else torch.empty)(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
+            dS = (torch.zeros if Tp != T else torch.empty)(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
+        else:
+            S = torch.empty(chunk * h, T, Tp, dtype=torch.float32, device=dev)
+            P = torch.empty(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
+            dP = torch.empty(chunk * h, T, Tp, dtype=torch.float32, device=dev)
+            dS = torch.empty(chunk * h, T, Tp, dtype=torch.bfloat16, device=dev)
         st = _s()
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             Z = nb * h
             row0 = b0 * T
             q_off, k_off, v_off = row0 * ld, row0 * ld + inner, row0 * ld + 2 * inner
-            # S = scale * Q K^T ;  P = softmax(S)
-            _gemm(qkv, qkv, S, lda=ld, ldb=ld, ldc=Tp, M=T, N=T, K=d, alpha=scale, batch1=nb, batch0=h, sA=(T * ld, d), sB=(T * ld, d),
-                  sC=(h * T * Tp, T * Tp), a_off=q_off, b_off=k_off)
-            check(lib().tribe_softmax_fwd(S.data_ptr(), Z * T, T, Tp, P.data_ptr(), Tp, Tp, st), "tribe_softmax_fwd")
-            # dP = dO V^T
-            _gemm(dout, qkv, dP, lda=inner, ldb=ld, ldc=Tp, M=T, N=T, K=d, batch1=nb, batch0=h, sA=(T * inner, d), sB=(T * ld, d),
-                  sC=(h * T * Tp, T * Tp), a_off=row0 * inner, b_off=v_off)
-            # dS = P * (dP - rowsum(P dP)) * scale
-            check(lib().tribe_softmax_bwd(P.data_ptr(), dP.data_ptr(), Z * T, T, Tp, Tp, Tp, scale, dS.data_ptr(), Tp, st), "tribe_softmax_bwd")
+            if fused:
+                # P = exp2(scale log2e Q K^T - lse2) ;  dS = (scale dO V^T - scale D) * P -- both straight out of the GEMM epilogues
+                _gemm(qkv, qkv, P, lda=ld, ldb=ld, ldc=Tp, M=T, N=T, K=d, alpha=scale * _LOG2E, act=_lib.ACT_EXP2, batch1=nb, batch0=h,
+                      sA=(T * ld, d), sB=(T * ld, d), sC=(h * T * Tp, T * Tp), a_off=q_off, b_off=k_off, row_bias=neg_lse, row_bias_off=b0 * h * T,
+                      sBias=(h * T, T))
+                _gemm(dout, qkv, dS, lda=inner, ldb=ld, ldc=Tp, M=T, N=T, K=d, alpha=scale, act=_lib.ACT_MUL_AUX, aux=P, ld_aux=Tp, batch1=nb,
+                      batch0=h, sA=(T * inner, d), sB=(T * ld, d), sC=(h * T * Tp, T * Tp), a_off=row0 * inner, b_off=v_off, row_bias=neg_d,
+                      row_bias_off=b0 * h * T, sBias=(h * T, T))
+            else:
+                # S = scale * Q K^T ;  P = softmax(S)
+                _gemm(qkv, qkv, S, lda=ld, ldb=ld, ldc=Tp, M=T, N=T, K=d, alpha=scale, batch1=nb, batch0=h, sA=(T * ld, d), sB=(T * ld, d),
+                      sC=(h * T * Tp, T * Tp), a_off=q_off, b_off=k_off)
+                check(lib().tribe_softmax_fwd(S.data_ptr(), Z * T, T, Tp, P.data_ptr(), Tp, Tp, st), "tribe_softmax_fwd")
+                # dP = dO V^T
+                _gemm(dout, qkv, dP, lda=inner, ldb=ld, ldc=Tp, M=T, N=T, K=d, batch1=nb, batch0=h, sA=(T * inner, d), sB=(T * ld, d),
+                      sC=(h * T * Tp, T * Tp), a_off=row0 * inner, b_off=v_off)
+                # dS = P * (dP - rowsum(P dP)) * scale
+                check(lib().tribe_softmax_bwd(P.data_ptr(), dP.data_ptr(), Z * T, T, Tp, Tp, Tp, scale, dS.data_ptr(), Tp, st), "tribe_softmax_bwd")
             # dQ[q, :] = sum_key dS[q, key] K[key, :]: the reduction runs along the rows of K -> per (b, h) transposed view [d, Tp]
             kT = _head_transpose(qkv, nb, h, T, d, ld, k_off)
             _gemm(dS, kT, dqkv, lda=Tp, ldb=Tp, ldc=ld, M=T, N=d, K=Tp, batch1=nb, batch0=h, sA=(h * T * Tp, T * Tp), sB=(h * d * Tp, d * Tp),
@@ -477,8 +518,7 @@ class RotaryAttention(torch.autograd.Function):
     def forward(ctx, qkv, cos, sin, neg_sin, B: int, T: int, heads: int, dim_head: int, scale: float, rot_dim: int, interleaved: bool):
         ctx.mark_dirty(qkv)
         ops.rotary_(qkv, T, heads, dim_head, rot_dim, cos, sin, interleaved)
-        out = ops.attention(qkv, B, T, heads, dim_head, scale)
-        ctx.save_for_backward(qkv)
+        out = Attention._fwd(ctx, qkv, B, T, heads, dim_head, scale)
         ctx.meta = (B, T, heads, dim_head, scale)
         ctx.rotary = (cos, neg_sin, rot_dim, interleaved)
         return out, qkv

@@ -17,7 +17,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libtribe_hip.so"
 
 F32, BF16, F64 = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU, ACT_GLU, ACT_GELU_BWD = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SILU, ACT_GLU, ACT_GELU_BWD, ACT_EXP2, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6, 7
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 ROLES = ["generic", "projector", "qkv", "attn_scores", "attn_pv", "out_proj", "ff1", "ff2", "voxel_head", "attention"]
 
@@ -50,6 +50,7 @@ class GemmDesc(C.Structure):
         ("aux", vp), ("ld_aux", i64), ("gather_b", i32),
         ("role", i32), ("tile_hint", i32), ("trans_ab", i32),
         ("c_bf16", vp), ("ld_c_bf16", i64), ("row_sumsq", vp), ("ld_row_sumsq", i64), ("row_scale", vp),
+        ("sBias0", i64),
     ]
 
 
@@ -61,6 +62,7 @@ class AttentionDesc(C.Structure):
         ("out", vp), ("ld_out", i64), ("B", i64), ("T", i64),
         ("heads_q", i32), ("heads_kv", i32), ("dim_head", i32), ("causal", i32), ("scale", f32),
         ("rel_qe", vp), ("ld_rel_qe", i64), ("rel_stride_h", i32), ("rel_left", i32), ("rel_right", i32),
+        ("lse", vp),
     ]
 
 
@@ -172,7 +174,7 @@ class EncoderDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # (struct name, mirror) in the order of tribe_abi_struct_sizes(): compared with the library's sizeof() at load time
 STRUCT_MIRRORS = [
     ("tribe_gemm_desc", GemmDesc), ("tribe_attention_desc", AttentionDesc), ("tribe_encoder_layer", EncoderLayer), ("tribe_encoder_desc", EncoderDesc),
@@ -233,6 +235,7 @@ SIGNATURES = {
     "tribe_transpose_f32_fwd": (C.c_int, [vp, i64, i64, i64, vp, vp]),
     "tribe_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "tribe_rownorm_scale_fwd": (C.c_int, [vp, i64, i64, vp, f32, f32, vp, vp]),
+    "tribe_rowdot_heads_bf16": (C.c_int, [vp, i64, vp, i64, i64, i64, i32, i32, f32, vp, vp]),
     "tribe_adam_chunk_elems": (i64, []),
     "tribe_adam_step": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, i32, vp]),
     "tribe_swa_update": (C.c_int, [vp, vp, vp, i64, f32, vp]),
@@ -245,6 +248,7 @@ SIGNATURES = {
     "tribe_llama_workspace_bytes": (sz, [C.POINTER(LlamaDesc)]),
     "tribe_llama_fwd": (C.c_int, [C.POINTER(LlamaDesc), vp, vp, sz, vp]),
     "tribe_attention_workspace_bytes": (sz, [i64, i64, i32, i32]),
+    "tribe_attention_lse_supported": (C.c_int, [i32, i32]),
     "tribe_attention_set_mode": (C.c_int, [i32]),
     "tribe_attention_fwd": (C.c_int, [vp, i64, i64, i32, i32, f32, vp, vp, sz, vp]),
     "tribe_encoder_workspace_bytes": (sz, [C.POINTER(EncoderDesc)]),

@@ -334,6 +334,44 @@ def attention(qkv: torch.Tensor, B: int, T: int, heads: int, dim_head: int, scal
     return out
 
 
+def attention_lse_supported(dim_head: int) -> bool:
+    """True when the fused bidirectional kernel of this head size can also write the base-2 log-sum-exp of its scores (attention_with_lse)."""
+    return bool(lib().tribe_attention_lse_supported(dim_head, 0))
+
+
+def attention_with_lse(qkv: torch.Tensor, B: int, T: int, heads: int, dim_head: int, scale: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """attention() plus lse2 [B, heads, T] f32 = log2 sum_j 2^(q.k_j * scale * log2 e): what a backward pass needs to rebuild
+    P = exp2(q.k * scale * log2 e - lse2) inside a GEMM epilogue (ACT_EXP2) instead of materialising f32 scores and a softmax."""
+    _cuda(qkv, torch.bfloat16, "qkv")
+    inner = heads * dim_head
+    if qkv.numel() != B * T * 3 * inner:
+        raise ValueError("attention_with_lse: qkv has the wrong number of elements")
+    out = torch.empty(B * T, inner, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, heads, T, dtype=torch.float32, device=qkv.device)
+    d = AttentionDesc()
+    base = qkv.data_ptr()
+    d.q, d.k, d.v = base, base + 2 * inner, base + 4 * inner
+    d.ld_q = d.ld_k = d.ld_v = 3 * inner
+    d.out, d.ld_out = out.data_ptr(), inner
+    d.B, d.T, d.heads_q, d.heads_kv, d.dim_head, d.causal, d.scale = B, T, heads, heads, dim_head, 0, scale
+    d.lse = lse.data_ptr()
+    check(lib().tribe_attention_fwd_ex(C.byref(d), _stream()), "tribe_attention_fwd_ex")
+    return out, lse
+
+
+def rowdot_heads(a: torch.Tensor, b: torch.Tensor, B: int, T: int, heads: int, dim_head: int, scale: float) -> torch.Tensor:
+    """out[b, h, t] = scale * sum_d a[b T + t, h dh + d] * b[b T + t, h dh + d] (bf16 [B*T, heads*dim_head] inputs, f32 output)."""
+    _cuda(a, torch.bfloat16, "a")
+    _cuda(b, torch.bfloat16, "b")
+    inner = heads * dim_head
+    if a.shape != (B * T, inner) or b.shape != (B * T, inner) or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError(f"rowdot_heads: operands must be contiguous [{B * T}, {inner}]")
+    out = torch.empty(B, heads, T, dtype=torch.float32, device=a.device)
+    check(lib().tribe_rowdot_heads_bf16(a.data_ptr(), inner, b.data_ptr(), inner, B, T, heads, dim_head, scale, out.data_ptr(), _stream()),
+          "tribe_rowdot_heads_bf16")
+    return out
+
+
 class EncoderPack:
     """Device-resident bf16 weights + f32 vectors of one x_transformers-style encoder, laid out for
     tribe_encoder_fwd.  Built from (and kept alive next to) the fp32 master parameters."""

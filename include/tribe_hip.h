@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TRIBE_ABI_VERSION 3   /* bumped whenever a descriptor struct changes layout (round 2 changed three without a bump) */
+#define TRIBE_ABI_VERSION 4   /* bumped whenever a descriptor struct changes layout (round 2 changed three without a bump) */
 
 enum tribe_dtype { TRIBE_F32 = 0, TRIBE_BF16 = 1, TRIBE_F64 = 2 };
 enum tribe_act {
@@ -39,7 +39,13 @@ enum tribe_act {
   TRIBE_ACT_SWIGLU = 2, /* columns come in (gate, up) pairs: out[:, j] = silu(v[:, 2j]) * v[:, 2j+1]; C has N/2 columns */
   TRIBE_ACT_SILU = 3,
   TRIBE_ACT_GLU = 4,    /* (a, b) column pairs: out[:, j] = v[:, 2j] * sigmoid(v[:, 2j+1]); C has N/2 columns (nn.GLU) */
-  TRIBE_ACT_GELU_BWD = 5 /* backward of GELU: out = v * gelu'(aux[m][n]), aux = saved pre-activation (bf16) */
+  TRIBE_ACT_GELU_BWD = 5, /* backward of GELU: out = v * gelu'(aux[m][n]), aux = saved pre-activation (bf16) */
+  /* attention backward without [B, h, T, T] f32 tensors (round 3): with alpha = scale * log2(e) and a ROW bias of -lse2 (the forward kernel's
+   * base-2 log-sum-exp) the score GEMM writes P = exp2(alpha * q.k - lse2[row]) directly ... */
+  TRIBE_ACT_EXP2 = 6,
+  /* ... and with alpha = scale and a row bias of -scale * D[row] (D = rowsum(dO * O)) the dP GEMM writes dS = (alpha * dO.v + bias[row]) * aux[m][n],
+   * aux = P (bf16, same layout AND batch strides as C) */
+  TRIBE_ACT_MUL_AUX = 7
 };
 enum tribe_bias_mode { TRIBE_BIAS_NONE = 0, TRIBE_BIAS_COL = 1, TRIBE_BIAS_ROW = 2 };
 /* which operator of the path a GEMM launch serves: selects the kernel SYMBOL (per-operator rows in
@@ -104,6 +110,7 @@ typedef struct tribe_gemm_desc {
   uint16_t* c_bf16; int64_t ld_c_bf16;
   float* row_sumsq; int64_t ld_row_sumsq;
   const float* row_scale;
+  int64_t sBias0;          /* + b0 * sBias0 on the bias pointer (a ROW bias per (b1, b0) batch: the attention backward's -lse2 / -scale * D); 0 = none */
 } tribe_gemm_desc;
 
 int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);
@@ -114,6 +121,12 @@ int tribe_gemm_sumsq_slots(const tribe_gemm_desc* desc);
  * GEMM epilogue left in row_sumsq (partial f32 [rows, n_partial], row-major). */
 int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partial, const float* g, float gain_scale, float eps,
                             float* scale, void* stream);
+
+/* D[row][h] = sum_d a[row][h * dim_head + d] * b[row][h * dim_head + d] * scale (bf16 inputs [rows, heads * dim_head], row strides in elements,
+ * f32 output [B, heads, T] with row = b * T + t): the rowsum(dO * O) term of the attention backward, written negated and pre-scaled as the row bias
+ * of the dS GEMM wants it when scale < 0. */
+int tribe_rowdot_heads_bf16(const uint16_t* a, int64_t ld_a, const uint16_t* b, int64_t ld_b, int64_t B, int64_t T, int32_t heads, int32_t dim_head,
+                            float scale, float* out, void* stream);
 
 /* Measurement hook (bench.py): while enabled, every GEMM launch is bracketed by HIP events on ITS
  * stream.  tribe_prof_end synchronises them and returns, per role, the summed kernel time (ms), the
@@ -199,8 +212,14 @@ typedef struct tribe_attention_desc {
    * score[i][j] += rel_qe[b*T + i][h * rel_stride_h + clamp(j - i, -rel_left, rel_right) + rel_left], where
    * rel_qe = q . distance_embedding^T (f32, computed by a GEMM beforehand).  NULL = none.  dim_head 64 only. */
   const float* rel_qe; int64_t ld_rel_qe; int32_t rel_stride_h, rel_left, rel_right;
+  /* optional: base-2 log-sum-exp of every query's scaled scores, f32 [B, heads_q, T]: lse2 = max + log2(sum 2^(s * scale * log2 e - max)), so
+   * that P = exp2(s * scale * log2 e - lse2) -- what a backward pass needs to recompute P without a softmax.  dim_head 384, bidirectional,
+   * default mode only (the one-wave-per-SIMD kernel): tribe_attention_fwd_ex fails otherwise.  NULL = not wanted. */
+  float* lse;
 } tribe_attention_desc;
 int tribe_attention_fwd_ex(const tribe_attention_desc* desc, void* stream);
+/* 1 when tribe_attention_fwd_ex can write desc->lse for this head size under the current tribe_attention_set_mode */
+int tribe_attention_lse_supported(int32_t dim_head, int32_t causal);
 
 typedef struct tribe_encoder_layer {
   /* attention block */

@@ -1,5 +1,5 @@
 """Training-step throughput (forward + backward + Adam) of the full-size TRIBE encoder on one MI355X.
-GPU box: python scripts/train_bench.py [B] [torch-adam] [graph] [--reference-defaults] [no-share]
+GPU box: python scripts/train_bench.py [B] [torch-adam] [graph] [--reference-defaults] [no-share] [no-fused-softmax] [attn-chunk=N]
   "graph": forward + backward replayed from one HIP graph.
   "--reference-defaults": the configuration the reference actually trains with (grids/defaults.py:95-141, main.py:199,337): batch 16,
       feature widths 2 x 3072 (Llama-3.2-3B) / 2 x 1024 (Wav2Vec-BERT) / 2 x 1408 (V-JEPA2 ViT-g), 298 feature steps pooled to 100 TRs,
@@ -41,7 +41,10 @@ use_graph = "graph" in sys.argv[1:]
 for _a in sys.argv[1:]:
     if _a.startswith("attn-chunk="):   # sequences per chunk of the materialised attention backward (experiment: keep S / P / dP / dS cache-resident)
         from modeling_utils import autograd as _ag
-        _ag.Attention.CHUNK_BYTES = int(_a.split("=")[1]) * 8 * 1024 * 1024 * 4
+        _ag.Attention.CHUNK_BYTES = _ag.Attention.CHUNK_BYTES_FUSED = int(_a.split("=")[1]) * 8 * 1024 * 1024 * 4
+if "no-fused-softmax" in sys.argv[1:]:   # attention backward through materialised f32 scores + softmax kernels (the round-2 path), for the A/B
+    from modeling_utils import autograd as _ag
+    _ag.Attention.FUSED_SOFTMAX = False
 opt = torch.optim.Adam(model.parameters(), lr=1e-4) if stock else HipAdam(model.parameters(), lr=1e-4)   # defaults.py:126-133
 g = torch.Generator().manual_seed(1)
 data = {m: torch.stack([torch.randn(l, d, T, generator=g).bfloat16() for _ in range(B)]).to(dev) for m, (l, d) in fdims.items()}

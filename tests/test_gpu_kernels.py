@@ -373,6 +373,75 @@ def test_attention(ops, B, T, h, d, mode):
     torch.testing.assert_close(out, want, rtol=2**-6, atol=3e-3)
 
 
+@pytest.mark.parametrize("B,T,h", [(2, 70, 3), (1, 298, 2), (2, 1024, 2), (1, 7, 1)])
+def test_attention_log_sum_exp_output(ops, B, T, h):
+    """tribe_attention_desc.lse (dim_head 384, one-wave-per-SIMD kernel): lse2[b, h, q] = log2 sum_j 2^(q.k_j scale log2e), i.e.
+    torch.logsumexp(scores) / ln 2, and the output is the same as without it.  Other head sizes / modes refuse the request."""
+    d = 384
+    g = torch.Generator().manual_seed(21)
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g))
+    if T == 1024:
+        qkv.view(B, T, 3, h, d)[0, 5, 0, 0] *= 6.0
+        qkv.view(B, T, 3, h, d)[0, 900, 1, 0] = bf(qkv.view(B, T, 3, h, d)[0, 5, 0, 0] * 0.5)
+        qkv = bf(qkv)   # (x 6 leaves the bf16 grid)
+    scale = d**-0.5
+    dev_qkv = _dev(qkv).bfloat16()
+    out, lse = ops.attention_with_lse(dev_qkv, B, T, h, d, scale)
+    assert torch.equal(out, ops.attention(dev_qkv, B, T, h, d, scale))
+    q, k, _ = (t.transpose(1, 2) for t in qkv.view(B, T, 3, h, d).unbind(2))
+    sim = torch.einsum("bhid,bhjd->bhij", q.double(), k.double()) * scale
+    want = torch.logsumexp(sim, dim=-1) / np.log(2.0)
+    torch.testing.assert_close(lse.cpu().double(), want, rtol=0, atol=2e-3)   # bf16 P in the running sum: ~2^-9 relative on the sum
+    assert not ops.attention_lse_supported(64) and not ops.attention_lse_supported(128)
+    ops.attention_set_mode(3)
+    try:
+        assert not ops.attention_lse_supported(384)
+        with pytest.raises(ValueError, match="log-sum-exp"):
+            ops.attention_with_lse(dev_qkv, B, T, h, d, scale)
+    finally:
+        ops.attention_set_mode(0)
+
+
+@pytest.mark.parametrize("nb,h,T,K", [(2, 3, 256, 128), (1, 2, 70, 64), (2, 2, 298, 384), (1, 1, 1024, 384), (3, 1, 300, 64)])
+def test_gemm_exp2_and_mul_aux_epilogues(ops, nb, h, T, K):
+    """The two epilogue operators of the attention backward, batched over (sequence, head) with a per-(sequence, head) ROW bias
+    (tribe_gemm_desc.sBias0): P = exp2(alpha a.b + bias[row]) and dS = (alpha a.b + bias[row]) * aux, aux addressed with C's batch strides.
+    T = 256 / 1024 run the wait-free whole-wave epilogue, 70 / 298 / 300 the per-row path (tiles that cross N, pad columns left untouched)."""
+    from modeling_utils import autograd as ag
+    from tribe_hip import _lib
+
+    g = torch.Generator().manual_seed(nb * 100 + T)
+    Tp = ops.round_up(T, 64)
+    a, b = bf(torch.randn(nb, h, T, K, generator=g)), bf(torch.randn(nb, h, T, K, generator=g))
+    bias = torch.randn(nb, h, T, generator=g)
+    alpha = 0.37 * K**-0.5
+    lin = alpha * torch.einsum("zhik,zhjk->zhij", a, b) + bias[..., None]
+    da, db, dbias = _dev(a).bfloat16().contiguous(), _dev(b).bfloat16().contiguous(), _dev(bias)
+    kw = dict(lda=K, ldb=K, ldc=Tp, M=T, N=T, K=K, alpha=alpha, batch1=nb, batch0=h, sA=(h * T * K, T * K), sB=(h * T * K, T * K),
+              sC=(h * T * Tp, T * Tp), row_bias=dbias, sBias=(h * T, T))
+    P = torch.full((nb, h, T, Tp), 7.0, dtype=torch.bfloat16, device="cuda")
+    ag._gemm(da, db, P, act=_lib.ACT_EXP2, **kw)
+    torch.testing.assert_close(P[..., :T].float().cpu(), torch.exp2(lin), rtol=2**-7, atol=1e-6)
+    assert (P[..., T:] == 7.0).all()
+    dS = torch.full((nb, h, T, Tp), 7.0, dtype=torch.bfloat16, device="cuda")
+    ag._gemm(da, db, dS, act=_lib.ACT_MUL_AUX, aux=P, ld_aux=Tp, **kw)
+    torch.testing.assert_close(dS[..., :T].float().cpu(), lin * P[..., :T].float().cpu(), rtol=2**-7, atol=1e-5)
+    assert (dS[..., T:] == 7.0).all()
+    with pytest.raises(ValueError, match="MUL_AUX"):
+        ag._gemm(da, db, dS, act=_lib.ACT_MUL_AUX, **kw)                                 # no aux
+    with pytest.raises(ValueError, match="row bias"):
+        ag._gemm(da, db, P, act=_lib.ACT_EXP2, bias=_dev(torch.zeros(T)), **{k: v for k, v in kw.items() if k not in ("row_bias", "sBias")})
+
+
+@pytest.mark.parametrize("B,T,h,d", [(2, 70, 3, 384), (1, 1024, 8, 384), (3, 33, 2, 64), (1, 5, 1, 1032)])
+def test_rowdot_heads(ops, B, T, h, d):
+    g = torch.Generator().manual_seed(5)
+    a, b = bf(torch.randn(B * T, h * d, generator=g)), bf(torch.randn(B * T, h * d, generator=g))
+    got = ops.rowdot_heads(_dev(a).bfloat16(), _dev(b).bfloat16(), B, T, h, d, -0.25).cpu()
+    want = -0.25 * (a.view(B, T, h, d).double() * b.view(B, T, h, d).double()).sum(-1).permute(0, 2, 1)
+    torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-4)
+
+
 # Transposed-operand GEMM (tribe_gemm_desc.trans_ab): C = At^T Bt, the weight-gradient form.  Whole tiles, ragged M / N (multiples of 8
 # only), one K-tile, a long reduction, bf16 output + bias.
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 1024), (3072, 1024, 4096), (264, 520, 128), (8, 16, 64), (1000, 296, 192)])

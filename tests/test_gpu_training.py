@@ -100,6 +100,44 @@ def test_attention_backward_with_and_without_explicit_transposes(B, T, h, d):
         assert _rel(got[:, :, i], want[:, :, i]) < 3e-2, name
 
 
+@pytest.mark.parametrize("B,T,h,chunk_seqs", [(2, 70, 2, 8), (3, 256, 3, 1), (2, 298, 2, 8), (3, 1024, 2, 2)])
+def test_attention_backward_without_f32_score_tensors(B, T, h, chunk_seqs):
+    """dim_head 384: the forward kernel hands over its base-2 log-sum-exp, the backward rebuilds P in the score GEMM's epilogue (ACT_EXP2) and
+    dS in the dO V^T GEMM's epilogue (ACT_MUL_AUX, D = rowsum(dO * O) as the row bias) -- no f32 [B h, T, T] tensor, no softmax kernel.
+    Against torch, and against the materialised path (FUSED_SOFTMAX = False) on the same inputs; T = 70 / 298 exercise the padded score
+    columns (T_pad 128 / 320) and the scalar epilogue path, chunk_seqs < B several chunks with their row-bias offsets."""
+    from modeling_utils import autograd as ag
+    from tribe_hip import ops
+
+    d = 384
+    assert ops.attention_lse_supported(d)
+    g = torch.Generator().manual_seed(15)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    qkv = bf(torch.randn(B * T, 3 * h * d, generator=g) * 0.7); dout = bf(torch.randn(B * T, h * d, generator=g))
+    qt = qkv.clone().requires_grad_()
+    q, k, v = (t.transpose(1, 2) for t in qt.view(B, T, 3, h, d).unbind(2))
+    att = (torch.einsum("bhid,bhjd->bhij", q, k) * d**-0.5).softmax(-1)
+    torch.einsum("bhij,bhjd->bhid", att, v).transpose(1, 2).reshape(B * T, h * d).backward(dout)
+    grads = {}
+    keep = ag.Attention.CHUNK_BYTES, ag.Attention.CHUNK_BYTES_FUSED, ag.Attention.FUSED_SOFTMAX
+    try:
+        ag.Attention.CHUNK_BYTES = ag.Attention.CHUNK_BYTES_FUSED = chunk_seqs * h * T * ops.round_up(T, 64) * 4
+        for fused in (True, False):
+            ag.Attention.FUSED_SOFTMAX = fused
+            qg = qkv.cuda().bfloat16().requires_grad_()
+            out = ag.Attention.apply(qg, B, T, h, d, d**-0.5)
+            assert (len(out.grad_fn.saved_tensors) == 3) == fused
+            out.backward(dout.cuda().bfloat16())
+            grads[fused] = qg.grad.float().cpu().view(B, T, 3, h, d)
+    finally:
+        ag.Attention.CHUNK_BYTES, ag.Attention.CHUNK_BYTES_FUSED, ag.Attention.FUSED_SOFTMAX = keep
+    want = qt.grad.view(B, T, 3, h, d)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert _rel(grads[True][:, :, i], want[:, :, i]) < 3e-2, name
+        assert _rel(grads[True][:, :, i], grads[False][:, :, i]) < 2e-2, name
+    assert torch.isfinite(grads[True]).all()
+
+
 @pytest.mark.parametrize("M,K,N", [(256, 128, 192), (320, 256, 136), (192, 128, 100)])
 def test_linear_weight_gradient_through_the_transposed_operand_gemm(M, K, N):
     """M % 64 == 0 with N, K >= 128 sends dW = dY^T X through tribe_gemm_desc.trans_ab (no explicit transposes; N = 136 pads dY's row
