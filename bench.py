@@ -399,6 +399,29 @@ def run_rank(args) -> None:
         dist.destroy_process_group()
 
 
+def _side_point(model, batch, ops, steps: int, warmup: int):
+    """(seconds per step WITHOUT the per-launch HIP events, role profile of a second, instrumented pass).  The event pair around every
+    GEMM / attention launch costs a step of a few milliseconds about 4 % (B = 4: 7.26 ms with, 6.98 ms without, profiles/r03_z8_r1_graph.txt;
+    replaying the step from a HIP graph gains nothing further), so the side points time clean steps and profile separately."""
+    import torch
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(batch)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ops.prof_begin(max_records=(steps + 1) * 128)
+        for _ in range(steps):
+            model(batch)
+        torch.cuda.synchronize()
+        prof = ops.prof_end()
+    return elapsed / steps, prof
+
+
 def r1_point(model, fdims, device, ops, steps: int = 30, warmup: int = 5) -> dict:
     """The BASELINE configuration un-stacked: B = 4 (one 1024-TR sequence per subject), same model, outside the timed
     headline.  Reported so the per-operator numbers (voxel head above all) exist at the literal config, where a launch has
@@ -406,21 +429,12 @@ def r1_point(model, fdims, device, ops, steps: int = 30, warmup: int = 5) -> dic
     import torch
 
     batch = make_batch(4, fdims, device, seed=7)
-    with torch.no_grad():
-        for _ in range(warmup):
-            model(batch)
-        torch.cuda.synchronize()
-        ops.prof_begin(max_records=(steps + 1) * 128)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            model(batch)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        prof = ops.prof_end()
+    per_step, prof = _side_point(model, batch, ops, steps, warmup)
     fl = flops_per_tr()
-    return {"workload": f"B=4 sequences (4 subjects x R=1) x T={T}", "value": round(4 * T * steps / elapsed, 1), "unit": "TRs/s",
-            "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
-            "whole_path_tflops": round(4 * T * steps * fl["total"] / elapsed / 1e12, 1), "by_kernel": _role_table(prof)}
+    return {"workload": f"B=4 sequences (4 subjects x R=1) x T={T}", "value": round(4 * T / per_step, 1), "unit": "TRs/s",
+            "steps": steps, "ms_per_step": round(per_step * 1e3, 3),
+            "whole_path_tflops": round(4 * T * fl["total"] / per_step / 1e12, 1), "by_kernel": _role_table(prof),
+            "by_kernel_source": "a second pass of the same steps with the per-launch HIP events on (they cost ~4 % at this step size; value is the clean pass)"}
 
 
 def config1_point(device, ops, steps: int = 50, warmup: int = 10) -> dict:
@@ -442,21 +456,11 @@ def config1_point(device, ops, steps: int = 50, warmup: int = 10) -> dict:
     data = {"text": torch.randn(1, L, D, 128, generator=g, device=device).to(torch.bfloat16),
             "subject_id": torch.zeros(1, 1, dtype=torch.long, device=device)}
     batch = SegmentData(data=data, segments=[None])
-    with torch.no_grad():
-        for _ in range(warmup):
-            model(batch)
-        torch.cuda.synchronize()
-        ops.prof_begin(max_records=(steps + 1) * 128)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            model(batch)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        prof = ops.prof_end()
+    per_step, prof = _side_point(model, batch, ops, steps, warmup)
     del model
     return {"workload": "BASELINE config 1: text-only, 1 subject, B=1 x T=128, hidden 3072 x 8 layers, V=1000 (audio / video absent)",
-            "value": round(128 * steps / elapsed, 1), "unit": "TRs/s", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
-            "by_kernel": _role_table(prof)}
+            "value": round(128 / per_step, 1), "unit": "TRs/s", "steps": steps, "ms_per_step": round(per_step * 1e3, 3),
+            "by_kernel": _role_table(prof), "by_kernel_source": "second, instrumented pass (see r1_point)"}
 
 
 def main() -> None:
