@@ -74,8 +74,27 @@ constexpr int SMEM_BYTES = 2 * BUF_BYTES;     // 128 KiB
 // 4 + NB loads in flight.
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Stream-K schedule of the transposed-operand (weight-gradient) form, desc.stream_k: the tiles of the last, PARTIAL round -- rem = tiles % W
+// on W CUs -- are cut into W equal runs of q = ceil(rem nk / W) K-steps, one per CU; a run that crosses a tile boundary is two workgroups (its
+// part of the first tile, its part of the next), so no workgroup loops.  blockIdx.x: [0, tiles_dp) whole tiles as ever; then W "first parts"
+// (worker w = index); then the "second parts" in DESCENDING length (second_worker[]), so that the dispatcher hands the CU whose first part
+// was shortest the longest second part -- every CU ends up with ~q K-steps.  A workgroup that holds a whole tile stores it; a partial one
+// leaves its accumulators in the workspace (slot 2 w + part, 256 KiB, in register order: 1 KiB per store instruction) and
+// streamk_reduce_kernel, launched behind it, sums the parts of every split tile IN ORDER (deterministic) and writes alpha * sum to C.
+// (First version: f32 atomics into a zeroed C -- the chip sustains only ~0.65 TB/s of them, ~100 us per 256-KiB part when every CU adds at
+// once; profiles/r03_z11_gemm_streamk.txt.)  dW of out-proj at B = 16: 144 tiles = 0.56 rounds -> 256 CUs busy.
+struct SkSched {
+  int tiles_dp;   // tiles (linear index < tiles_dp) computed whole; >= tiles_m * tiles_n: no stream-K
+  int rem_units;  // K-steps of the stream-K region: (tiles - tiles_dp) * nk
+  int q;          // K-steps per worker
+  int workers;
+  float* ws;      // 2 * workers slots of 256 x 256 f32
+  unsigned short second_worker[256];
+};
+constexpr int SK_SLOT_FLOATS = 256 * 256;
+
 template <int OUT_BF16, int ROLE, int TN = 0, int NB = 4>
-__global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_desc g, int tiles_m, int tiles_n, const SkSched sk) {
   static_assert(NB >= 2 && NB <= 4 && (!TN || NB == 4), "tile columns: 128, 192 or 256; transposed operands: 256 only");
   constexpr int BM = big::BM, BN = 64 * NB, A_BYTES = big::A_BYTES, BUF_BYTES = A_BYTES + BN * BK * 2;
   constexpr int WN = 16 * NB;                      // columns per wave
@@ -86,8 +105,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
   const int wr = wave >> 2, wc = wave & 3;
 
+  // which tile, which K-steps of it [k_first, k_first + nk), and whether that is the whole tile
+  int tile_lin = (int)blockIdx.x, k_first = 0, nk = (int)(g.K / BK);
+  bool partial = false;
+  int sk_slot = 0;
+  if constexpr (TN) {
+    if ((int)blockIdx.x >= sk.tiles_dp) {
+      const int sidx = (int)blockIdx.x - sk.tiles_dp;
+      const bool second = sidx >= sk.workers;
+      const int w = second ? (int)sk.second_worker[sidx - sk.workers] : sidx;
+      const int u0 = w * sk.q;
+      if (u0 >= sk.rem_units) return;                                    // (ceil: the last workers may have nothing)
+      const int run = min(sk.q, sk.rem_units - u0);
+      const int t_loc = u0 / nk, x = u0 - t_loc * nk, first_len = min(run, nk - x);
+      if (second && first_len >= run) return;                            // this worker's run stays inside one tile
+      tile_lin = sk.tiles_dp + t_loc + (second ? 1 : 0);
+      k_first = second ? 0 : x;
+      const int len = second ? run - first_len : first_len;
+      partial = len != nk;
+      nk = len;
+      sk_slot = 2 * w + (second ? 1 : 0);
+    }
+  }
   int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  tile_coords(tile_lin, tiles_m, tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int64_t z = blockIdx.y;
@@ -283,7 +324,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   TRIBE_STAMP(ts5);                                        \
   TRIBE_STAMP_ACC(1, ts1, ts2); TRIBE_STAMP_ACC(2, ts2, ts3); TRIBE_STAMP_ACC(3, ts3, ts4); TRIBE_STAMP_ACC(4, ts4, ts5);
 
-  const int nk = (int)(g.K / BK);
   // K rotation: the workgroups that share an operand panel in an XCD's L2 (the 4 x 8 patch of tile_coords) walk K from different
   // starting K-tiles, one apart, and wrap around.  Walking in lockstep, all sharers of a line wait on the SAME fill from beyond L2;
   // one K-tile apart, the first brings the line in and the others hit (profiles/r03_b_gemm_ablation.txt: with every load an L2 hit
@@ -296,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
 #endif
   // (Also tried, profiles/r03_h_gemm_kperm.txt: a cyclic shift inside every window of 8 K-tiles, which spreads the first touches evenly
   // over the sharers instead of leaving them to the one that walks ahead -- FF1 / FF2 / QKV within +-0.7 % of the plain rotation.)
-  auto ktile = [&](int t) { const int k = t + krot; return k >= nk ? k - nk : k; };
+  auto ktile = [&](int t) { const int k = t + krot; return k_first + (k >= nk ? k - nk : k); };
 #ifdef TRIBE_GEMM_STAMPS
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
   unsigned long long stamp_acc[5] = {0, 0, 0, 0, 0};  // 0 LDS reads, 1 stage + vmcnt wait, 2 barrier 1, 3 MFMA cluster, 4 barrier 2
@@ -364,6 +404,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
   // through LDS to get whole-row 256-byte stores was measured 2x SLOWER (K = 64 probe: 158 vs 75 us f32, 138 vs 43 us
   // bf16 per 16384 x 3072 output): the extra LDS round trip costs more than the wider store segments save.
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
+  if constexpr (TN && !OUT_BF16) {
+    if (partial) {
+      // part of a tile's reduction (stream-K): the raw accumulators go to this part's workspace slot in register order
+      float* slot = sk.ws + (int64_t)sk_slot * SK_SLOT_FLOATS + tid * 4;
+      static_for<8 * NB>([&](auto t) {
+        constexpr int i = decltype(t)::value / NB, j = decltype(t)::value % NB;
+        *(f32x4_t*)(slot + (i * NB + j) * 2048) = acc[i][j];
+      });
+      return;
+    }
+  }
   if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
     // nothing inside the sub-tile loop waits on memory (gemm_common.h); the staging buffers are idle by now
     epilogue_fast<OUT_BF16, 8, NB, (ROLE == TRIBE_ROLE_EXT), TACC>(g, ctx, acc, m0 + wr * 128, n0 + wc * WN, lane, smem + wave * (4 * NB * 1024));
@@ -373,6 +424,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256x256x64(const tribe_gemm_de
     constexpr int i = decltype(t)::value / NB, j = decltype(t)::value % NB;
     epilogue_tile16<OUT_BF16, (ROLE == TRIBE_ROLE_EXT), TACC>(g, ctx, acc[i][j], m0 + wr * 128 + i * 16, n0 + wc * WN + j * 16, lane);
   });
+}
+
+// Second launch of a stream-K GEMM: workgroup t sums the parts of tile tiles_dp + t in worker order (first parts and second parts of the runs
+// that touch it) and writes alpha * sum.  Thread tid holds the same 128 values the GEMM kernel's thread tid held: accumulator register r of
+// sub-tile (i, j) of lane l is D[4 (l >> 4) + r][l & 15] of the 16 x 16 sub-tile at rows wr 128 + 16 i, columns wc 64 + 16 j.
+__global__ __launch_bounds__(512) void streamk_reduce_kernel(const tribe_gemm_desc g, int tiles_m, int tiles_n, const SkSched sk) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+  const int nk = (int)(g.K / BK);
+  const int t_loc = (int)blockIdx.x;
+  const int u_lo = t_loc * nk, u_hi = u_lo + nk - 1;
+  const int w_lo = u_lo / sk.q, w_hi = u_hi / sk.q;
+  if (w_lo == w_hi) return;   // one run holds the whole tile: stored by the GEMM kernel itself
+  int tm, tn;
+  tile_coords(sk.tiles_dp + t_loc, tiles_m, tiles_n, tm, tn);
+  const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+  float* C = (float*)g.C;
+  for (int sub = 0; sub < 32; ++sub) {
+    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+    for (int w = w_lo; w <= w_hi; ++w) {
+      const int part = w * sk.q < u_lo ? 1 : 0;   // the run began in the previous tile: this tile holds its second part
+      sum += *(const f32x4_t*)(sk.ws + (int64_t)(2 * w + part) * SK_SLOT_FLOATS + sub * 2048 + tid * 4);
+    }
+    const int i = sub >> 2, j = sub & 3;
+    const int64_t col = n0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = m0 + wr * 128 + i * 16 + 4 * (lane >> 4) + r;
+      if (row < g.M && col < g.N) C[row * g.ldc + col] = sum[r] * g.alpha;
+    }
+  }
 }
 
 // =============================================================================================
@@ -1000,15 +1081,15 @@ enum { KIND_SMALL = 0, KIND_BIG = 1, KIND_RING = 2, KIND_BIG4W = 3 };
   X(4, 0, TRIBE_ROLE_PROJECTOR) X(5, 1, TRIBE_ROLE_QKV) X(6, 0, TRIBE_ROLE_ATTN_SCORES) X(7, 1, TRIBE_ROLE_ATTN_PV)    \
   X(8, 0, TRIBE_ROLE_OUT_PROJ) X(9, 1, TRIBE_ROLE_FF1) X(10, 0, TRIBE_ROLE_FF2) X(11, 0, TRIBE_ROLE_VOXEL_HEAD)
 void launch_big4(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
-void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n, const SkSched& sk);
 void launch_big3(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_ring(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_4w(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_small(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 
 // the dynamic-LDS attribute is set once per kernel AND device (one process may drive several GPUs)
-template <auto KERNEL, int THREADS, int SMEM>
-static void launch_k(dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n) {
+template <auto KERNEL, int THREADS, int SMEM, class... Extra>
+static void launch_k(dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n, const Extra&... extra) {
   static bool attr_done[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1016,7 +1097,11 @@ static void launch_k(dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int til
     (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
-  hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS, 1, 1), SMEM, s, *d, tiles_m, tiles_n);
+  hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS, 1, 1), SMEM, s, *d, tiles_m, tiles_n, extra...);
+}
+inline const SkSched& no_stream_k() {
+  static const SkSched none = [] { SkSched k{}; k.tiles_dp = 0x7fffffff; return k; }();
+  return none;
 }
 #define TRIBE_GEMM_TABLE(NAME)                                                                                         \
   void NAME(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n) {                  \
@@ -1027,16 +1112,16 @@ static void launch_k(dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int til
   }
 #if TRIBE_GEMM_HAS_PART(0)
 #define TRIBE_GEMM_CASE_launch_big4(idx, bf, role) \
-  case idx: launch_k<gemm_nt_256x256x64<bf, role, 0, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
+  case idx: launch_k<gemm_nt_256x256x64<bf, role, 0, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n, no_stream_k()); break;
 TRIBE_GEMM_TABLE(launch_big4)
-void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n) {
-  if (bf) launch_k<gemm_nt_256x256x64<1, TRIBE_ROLE_GENERIC, 1, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n);
-  else launch_k<gemm_nt_256x256x64<0, TRIBE_ROLE_GENERIC, 1, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n);
+void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n, const SkSched& sk) {
+  if (bf) launch_k<gemm_nt_256x256x64<1, TRIBE_ROLE_GENERIC, 1, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n, sk);
+  else launch_k<gemm_nt_256x256x64<0, TRIBE_ROLE_GENERIC, 1, 4>, 512, big::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n, sk);
 }
 #endif
 #if TRIBE_GEMM_HAS_PART(1)
 #define TRIBE_GEMM_CASE_launch_big3(idx, bf, role) \
-  case idx: launch_k<gemm_nt_256x256x64<bf, role, 0, 3>, 512, 2 * (big::A_BYTES + 192 * BK * 2)>(grid, s, d, tiles_m, tiles_n); break;
+  case idx: launch_k<gemm_nt_256x256x64<bf, role, 0, 3>, 512, 2 * (big::A_BYTES + 192 * BK * 2)>(grid, s, d, tiles_m, tiles_n, no_stream_k()); break;
 TRIBE_GEMM_TABLE(launch_big3)
 #endif
 #if TRIBE_GEMM_HAS_PART(2)
@@ -1240,6 +1325,54 @@ static GemmPlan gemm_plan(const tribe_gemm_desc* d) {
 }
 }  // namespace tribe_gemm_detail
 
+namespace tribe_gemm_detail {
+// Stream-K plan of a launch with `tiles` output tiles of nk K-steps each (see SkSched): fills *sk and returns the grid size.  Whole rounds of
+// W tiles stay whole; the remainder is cut into W runs.  Not worth it (or not possible) -> the plain grid.
+unsigned plan_stream_k(int tiles, int nk, SkSched* sk) {
+  static int cus[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  const int W = cus[dev] < 256 ? cus[dev] : 256;
+  const int rem = tiles % W;
+  *sk = no_stream_k();
+  // Worth it only for remainders up to half a round.  Measured at B = 16 (profiles/r03_z12_gemm_streamk.txt, same numbers with atomics and
+  // with the workspace): remainder 64 of 256 (dW of FF1 / FF2: 576 tiles; the projectors: 64 tiles) 1284 -> 1076 us / 1294 -> 1086 us /
+  // 328 -> 161 us -- there a run is a clean quarter of a tile; remainder 176 (QKV) 848 -> 1007 us and 144 (out-proj) 334 -> 439 us: SLOWER --
+  // every run straddles two tiles at its own K offset, so the 32 workgroups of an XCD stop sharing operand panels in its L2 (the 4 x 8 patch
+  // of tile_coords) and the region turns memory-bound; and every part pays a prologue + epilogue (~45 us) for at most 1/2 tile of work.
+  // Also: runs of at least 8 K-steps.
+  if (rem == 0 || rem * 2 > W || (int64_t)rem * nk < (int64_t)W * 8) return (unsigned)tiles;
+  sk->tiles_dp = tiles - rem;
+  sk->rem_units = rem * nk;
+  sk->q = (sk->rem_units + W - 1) / W;
+  sk->workers = W;
+  // second parts, longest first
+  int len2[256], n2 = 0;
+  unsigned short who[256];
+  for (int w = 0; w < W; ++w) {
+    const int u0 = w * sk->q;
+    if (u0 >= sk->rem_units) break;
+    const int run = sk->q < sk->rem_units - u0 ? sk->q : sk->rem_units - u0;
+    const int x = u0 % nk, first = run < nk - x ? run : nk - x;
+    if (first < run) { len2[n2] = run - first; who[n2] = (unsigned short)w; ++n2; }
+  }
+  for (int i = 1; i < n2; ++i) {   // insertion sort, descending, stable
+    const int l = len2[i]; const unsigned short v = who[i];
+    int j = i - 1;
+    for (; j >= 0 && len2[j] < l; --j) { len2[j + 1] = len2[j]; who[j + 1] = who[j]; }
+    len2[j + 1] = l; who[j + 1] = v;
+  }
+  for (int i = 0; i < n2; ++i) sk->second_worker[i] = who[i];
+  return (unsigned)(sk->tiles_dp + W + n2);
+}
+}  // namespace tribe_gemm_detail
+
 extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   TRIBE_REQUIRE(d != nullptr, "tribe_gemm_bf16: null descriptor");
   TRIBE_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "tribe_gemm_bf16: M, N, K must be positive (got %lld %lld %lld)",
@@ -1303,7 +1436,21 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   const int slot = prof_before(role, flops, s);
   const bool bf = d->c_dtype == TRIBE_BF16;
   if (d->trans_ab) {   // transposed operands: the 256^2 kernel only, plain epilogue operators
-    tribe_gemm_detail::launch_big4_tn(bf ? 1 : 0, grid, s, d, (int)tiles_m, (int)tiles_n);
+    SkSched sk = tribe_gemm_detail::no_stream_k();
+    if (d->stream_k) {
+      TRIBE_REQUIRE(!bf && nz == 1 && d->bias_mode == TRIBE_BIAS_NONE && d->act == TRIBE_ACT_NONE && !d->res && !d->rowadd && !d->gadd,
+                    "tribe_gemm_bf16: stream_k takes a plain un-batched f32 product");
+      grid.x = tribe_gemm_detail::plan_stream_k((int)(tiles_m * tiles_n), (int)(d->K / BK), &sk);
+      if (sk.tiles_dp < tiles_m * tiles_n) {
+        const int64_t need = (int64_t)2 * sk.workers * SK_SLOT_FLOATS * 4;
+        TRIBE_REQUIRE(d->stream_k_ws && d->stream_k_ws_bytes >= need && ((uintptr_t)d->stream_k_ws % 16) == 0,
+                      "tribe_gemm_bf16: stream_k needs a 16-byte aligned workspace of %lld bytes (tribe_gemm_stream_k_workspace_bytes)", (long long)need);
+        sk.ws = (float*)d->stream_k_ws;
+      }
+    }
+    tribe_gemm_detail::launch_big4_tn(bf ? 1 : 0, grid, s, d, (int)tiles_m, (int)tiles_n, sk);
+    if (sk.tiles_dp < tiles_m * tiles_n)
+      hipLaunchKernelGGL(streamk_reduce_kernel, dim3((unsigned)(tiles_m * tiles_n - sk.tiles_dp)), dim3(512), 0, s, *d, (int)tiles_m, (int)tiles_n, sk);
     prof_after(slot, s);
     TRIBE_LAUNCH_CHECK();
     return 0;
@@ -1335,6 +1482,15 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   prof_after(slot, s);
   TRIBE_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int64_t tribe_gemm_stream_k_workspace_bytes(const tribe_gemm_desc* d) {
+  TRIBE_REQUIRE(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0 && d->K % BK == 0, "tribe_gemm_stream_k_workspace_bytes: bad descriptor");
+  if (!d->trans_ab || !d->stream_k || d->batch1 * d->batch0 != 1) return 0;
+  SkSched sk;
+  const int tiles = (int)(((d->M + 255) / 256) * ((d->N + 255) / 256));
+  if (tribe_gemm_detail::plan_stream_k(tiles, (int)(d->K / BK), &sk) == (unsigned)tiles) return 0;
+  return (int64_t)2 * sk.workers * SK_SLOT_FLOATS * 4;
 }
 
 extern "C" int tribe_gemm_sumsq_slots(const tribe_gemm_desc* d) {

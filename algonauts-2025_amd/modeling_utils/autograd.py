@@ -34,10 +34,12 @@ def _s() -> int:
 def _gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, lda=None, ldb=None, ldc=None, M=None, N=None, K=None, alpha=1.0,
           bias=None, act=_lib.ACT_NONE, aux=None, res=None, ldres=None, res_scale=None, batch1=1, batch0=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
           gather1=None, gather_a=False, gather_b=False, a_off=0, b_off=0, c_off=0, role=0, trans_ab=False, row_bias=None, row_bias_off=0,
-          sBias=(0, 0), ld_aux=None) -> None:
-    """Thin positional wrapper over tribe_gemm_bf16 (element offsets allow strided views without copies)."""
+          sBias=(0, 0), ld_aux=None, stream_k=False) -> None:
+    """Thin positional wrapper over tribe_gemm_bf16 (element offsets allow strided views without copies).
+    stream_k (trans_ab only): let the launcher cut the last partial round of tiles over all CUs (workspace taken from ops.workspace)."""
     d = GemmDesc()
     d.trans_ab = int(trans_ab)
+    d.stream_k = int(stream_k)
     d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, batch1, batch0
     d.A, d.lda, d.sA1, d.sA0 = a.data_ptr() + 2 * a_off, lda, sA[0], sA[1]
     d.B, d.ldb, d.sB1, d.sB0 = b.data_ptr() + 2 * b_off, ldb, sB[0], sB[1]
@@ -56,6 +58,11 @@ def _gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, lda=None, ldb=
         d.res_scale = res_scale.data_ptr()
     if gather1 is not None:
         d.gather1, d.gather_a, d.gather_b = gather1.data_ptr(), int(gather_a), int(gather_b)
+    if stream_k:
+        nbytes = lib().tribe_gemm_stream_k_workspace_bytes(C.byref(d))
+        if nbytes > 0:   # parts of split tiles travel through the workspace; a second launch sums them in order
+            ws = ops.workspace(nbytes, out.device, tag="streamk")
+            d.stream_k_ws, d.stream_k_ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     check(lib().tribe_gemm_bf16(C.byref(d), _s()), "tribe_gemm_bf16")
 
 
@@ -83,12 +90,17 @@ def grad_sums_and_cast(dy: torch.Tensor, M: int, N: int, res: torch.Tensor | Non
     return sa, sab, bf
 
 
+# weight gradients through the stream-K schedule of the transposed-operand GEMM (tribe_gemm_desc.stream_k): dW of a 3072 x 3072 layer is 144
+# tiles on 256 CUs, of a 12288 x 3072 one 576 = 2.25 rounds.  Split tiles are summed in a fixed order: bit-reproducible.
+STREAM_K_WGRAD = True
+
+
 def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, M: int, N: int, K: int, ld_dy: int, ld_x: int) -> None:
     """dw[n, k] = sum_m dy[m, n] x[m, k]  (dy bf16 [M, ld_dy >= N], x bf16 [M, ld_x >= K], dw f32 [N, K]): the weight gradient of a Linear.
     Shapes the 256^2 kernel covers go through its transposed-operand form (desc.trans_ab: dy and x are read as they lie, the LDS reads
     transpose); the rest keep the two explicit bf16 transposes in front of the NT GEMM."""
     if M % 64 == 0 and N % 8 == 0 and K % 8 == 0 and N >= 128 and K >= 128 and ld_dy % 8 == 0 and ld_x % 8 == 0:
-        _gemm(dy, x, dw, lda=ld_dy, ldb=ld_x, ldc=K, M=N, N=K, K=M, trans_ab=True)
+        _gemm(dy, x, dw, lda=ld_dy, ldb=ld_x, ldc=K, M=N, N=K, K=M, trans_ab=True, stream_k=STREAM_K_WGRAD)
         return
     dy_t = transpose_bf16(dy, 1, M, N, 0, ld_dy)[0]   # [N, M_pad]
     x_t = transpose_bf16(x, 1, M, K, 0, ld_x)[0]      # [K, M_pad]

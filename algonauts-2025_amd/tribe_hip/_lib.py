@@ -51,6 +51,7 @@ class GemmDesc(C.Structure):
         ("role", i32), ("tile_hint", i32), ("trans_ab", i32),
         ("c_bf16", vp), ("ld_c_bf16", i64), ("row_sumsq", vp), ("ld_row_sumsq", i64), ("row_scale", vp),
         ("sBias0", i64),
+        ("stream_k", i32), ("reserved0", i32), ("stream_k_ws", vp), ("stream_k_ws_bytes", i64),
     ]
 
 
@@ -174,7 +175,7 @@ class EncoderDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # (struct name, mirror) in the order of tribe_abi_struct_sizes(): compared with the library's sizeof() at load time
 STRUCT_MIRRORS = [
     ("tribe_gemm_desc", GemmDesc), ("tribe_attention_desc", AttentionDesc), ("tribe_encoder_layer", EncoderLayer), ("tribe_encoder_desc", EncoderDesc),
@@ -191,6 +192,7 @@ SIGNATURES = {
     "tribe_last_error": (C.c_char_p, []),
     "tribe_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "tribe_gemm_sumsq_slots": (C.c_int, [C.POINTER(GemmDesc)]),
+    "tribe_gemm_stream_k_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
     "tribe_prof_begin": (C.c_int, [i32]),
     "tribe_prof_end": (C.c_int, [i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "tribe_pack_weight_bf16": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),

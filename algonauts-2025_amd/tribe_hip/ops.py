@@ -110,9 +110,10 @@ def gemm_nt(
 
 
 def gemm_tn(at: torch.Tensor, bt: torch.Tensor, *, out_dtype: torch.dtype = torch.float32, alpha: float = 1.0,
-            bias: torch.Tensor | None = None) -> torch.Tensor:
+            bias: torch.Tensor | None = None, stream_k: bool = False) -> torch.Tensor:
     """out[m, n] = alpha * sum_k at[k, m] * bt[k, n] (+ bias[n]); at bf16 [K, M], bt bf16 [K, N], K % 64 == 0, M and N multiples of 8
-    (tribe_gemm_desc.trans_ab: the weight-gradient form dW = dY^T X without explicit transposes)."""
+    (tribe_gemm_desc.trans_ab: the weight-gradient form dW = dY^T X without explicit transposes).  stream_k: the launcher may cut the
+    last partial round of tiles over all CUs (plain f32 product only); gemm_tn.last_split tells whether it did."""
     _cuda(at, torch.bfloat16, "at")
     _cuda(bt, torch.bfloat16, "bt")
     if at.ndim != 2 or bt.ndim != 2 or at.shape[0] != bt.shape[0]:
@@ -126,8 +127,17 @@ def gemm_tn(at: torch.Tensor, bt: torch.Tensor, *, out_dtype: torch.dtype = torc
     d.C, d.ldc, d.c_dtype, d.alpha, d.trans_ab = out.data_ptr(), N, _DT[out_dtype], alpha, 1
     if bias is not None:
         d.bias, d.bias_mode = _cuda(bias, torch.float32, "bias").data_ptr(), _lib.BIAS_COL
+    d.stream_k = int(stream_k)
+    nbytes = lib().tribe_gemm_stream_k_workspace_bytes(C.byref(d)) if stream_k else 0
+    gemm_tn.last_split = nbytes > 0
+    if nbytes > 0:   # parts of split tiles travel through the workspace; a second launch sums them in order
+        ws = workspace(nbytes, at.device, tag="streamk")
+        d.stream_k_ws, d.stream_k_ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     check(lib().tribe_gemm_bf16(C.byref(d), _stream()), "tribe_gemm_bf16")
     return out
+
+
+gemm_tn.last_split = False
 
 
 # --------------------------------------------------------------------------------------

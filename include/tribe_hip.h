@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TRIBE_ABI_VERSION 4   /* bumped whenever a descriptor struct changes layout (round 2 changed three without a bump) */
+#define TRIBE_ABI_VERSION 5   /* bumped whenever a descriptor struct changes layout (round 2 changed three without a bump) */
 
 enum tribe_dtype { TRIBE_F32 = 0, TRIBE_BF16 = 1, TRIBE_F64 = 2 };
 enum tribe_act {
@@ -111,12 +111,21 @@ typedef struct tribe_gemm_desc {
   float* row_sumsq; int64_t ld_row_sumsq;
   const float* row_scale;
   int64_t sBias0;          /* + b0 * sBias0 on the bias pointer (a ROW bias per (b1, b0) batch: the attention backward's -lse2 / -scale * D); 0 = none */
+  /* trans_ab only (the weight-gradient form, whose few output tiles rarely fill the chip: dW of a 3072 x 3072 layer is 144 tiles on 256 CUs):
+   * 1 = the launcher may cut the reduction of the last, partial round of tiles into equal runs over all CUs (stream-K).  Workgroups that hold
+   * part of a tile leave their accumulators in stream_k_ws; a second launch on the same stream sums the parts of each split tile in a fixed
+   * order (bit-reproducible) and writes C.  Plain f32 product only (no bias / activation / residual / batch).  The workspace must hold
+   * tribe_gemm_stream_k_workspace_bytes(desc) bytes (0 = this launch is not split), 16-byte aligned, and is free again when the launch is done. */
+  int32_t stream_k; int32_t reserved0;
+  void* stream_k_ws; int64_t stream_k_ws_bytes;
 } tribe_gemm_desc;
 
 int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);
 /* number of row_sumsq slots per row the launch of `desc` writes (N / 64, or N / 48 when the launch gets 256 x 192 tiles); < 0 on a bad
  * descriptor.  Depends on M, N, K, the batch counts, tile_hint and the fused-norm operands only. */
 int tribe_gemm_sumsq_slots(const tribe_gemm_desc* desc);
+/* bytes of desc->stream_k_ws this launch needs: 0 when it would not be split (stream_k clear, not trans_ab, or no partial round worth cutting) */
+int64_t tribe_gemm_stream_k_workspace_bytes(const tribe_gemm_desc* desc);
 /* scale[m] = g[0] * gain_scale / max(sqrt(sum_p partial[m, p]), eps): the ScaleNorm factor from the partial sums of squares a
  * GEMM epilogue left in row_sumsq (partial f32 [rows, n_partial], row-major). */
 int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partial, const float* g, float gain_scale, float eps,

@@ -1,5 +1,5 @@
 """Training-step throughput (forward + backward + Adam) of the full-size TRIBE encoder on one MI355X.
-GPU box: python scripts/train_bench.py [B] [torch-adam] [graph] [--reference-defaults] [no-share] [no-fused-softmax] [attn-chunk=N]
+GPU box: python scripts/train_bench.py [B] [torch-adam] [graph] [--reference-defaults] [no-share] [no-fused-softmax] [no-stream-k] [attn-chunk=N]
   "graph": forward + backward replayed from one HIP graph.
   "--reference-defaults": the configuration the reference actually trains with (grids/defaults.py:95-141, main.py:199,337): batch 16,
       feature widths 2 x 3072 (Llama-3.2-3B) / 2 x 1024 (Wav2Vec-BERT) / 2 x 1408 (V-JEPA2 ViT-g), 298 feature steps pooled to 100 TRs,
@@ -42,6 +42,9 @@ for _a in sys.argv[1:]:
     if _a.startswith("attn-chunk="):   # sequences per chunk of the materialised attention backward (experiment: keep S / P / dP / dS cache-resident)
         from modeling_utils import autograd as _ag
         _ag.Attention.CHUNK_BYTES = _ag.Attention.CHUNK_BYTES_FUSED = int(_a.split("=")[1]) * 8 * 1024 * 1024 * 4
+if "no-stream-k" in sys.argv[1:]:   # weight gradients on whole tiles only (the round-2 schedule), for the A/B of tribe_gemm_desc.stream_k
+    from modeling_utils import autograd as _ag
+    _ag.STREAM_K_WGRAD = False
 if "no-fused-softmax" in sys.argv[1:]:   # attention backward through materialised f32 scores + softmax kernels (the round-2 path), for the A/B
     from modeling_utils import autograd as _ag
     _ag.Attention.FUSED_SOFTMAX = False

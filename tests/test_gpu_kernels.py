@@ -458,6 +458,29 @@ def test_gemm_transposed_operands(ops, M, N, K):
         ops.gemm_tn(_dev(at[:, : M - 3].contiguous()).bfloat16(), _dev(bt).bfloat16())   # M not a multiple of 8
 
 
+# Stream-K schedule of the transposed-operand GEMM (tribe_gemm_desc.stream_k): shapes whose tile count leaves at most half a round on 256 CUs --
+# 6 tiles (ragged M / N), 120 tiles of 136 K-steps (runs of 64 K-steps: most cross a tile boundary), 272 tiles (one whole round stored plainly
+# + 16 tiles cut into 256 runs) -- and two that are left alone (4 tiles x 2 K-steps; 144 tiles = more than half a round).
+@pytest.mark.parametrize("M,N,K,splits", [(264, 520, 22016, True), (2560, 3072, 8704, True), (4352, 4096, 8192, True), (512, 512, 128, False),
+                                          (3072, 3072, 4096, False)])
+def test_gemm_transposed_operands_stream_k(ops, M, N, K, splits):
+    g = torch.Generator().manual_seed(M + K)
+    at, bt = _dev(torch.randn(K, M, generator=g)).bfloat16(), _dev(torch.randn(K, N, generator=g)).bfloat16()
+    whole = ops.gemm_tn(at, bt, alpha=0.5)
+    split = ops.gemm_tn(at, bt, alpha=0.5, stream_k=True)
+    assert ops.gemm_tn.last_split == splits
+    # same products, f32 accumulation in a different order: K^0.5 * 2^-24-sized differences on K^0.5-sized sums
+    torch.testing.assert_close(split, whole, rtol=2e-5, atol=2e-5 * K**0.5)
+    if not splits:
+        assert torch.equal(split, whole)
+    for _ in range(3):   # the parts of a split tile are summed in a fixed order: bit-reproducible
+        assert torch.equal(ops.gemm_tn(at, bt, alpha=0.5, stream_k=True), split)
+    ref = 0.5 * (at[:, :64].float().t() @ bt[:, :96].float())
+    torch.testing.assert_close(split[:64, :96], ref, rtol=1e-4, atol=1e-3 * K**0.5)
+    with pytest.raises(ValueError, match="stream_k"):
+        ops.gemm_tn(at, bt, stream_k=True, bias=_dev(torch.zeros(N)))
+
+
 # dim_head 64 (the extractors) on the 64-row-per-wave kernels (mode 4: four waves; mode 5: anti-phase wave pairs; mode 0 picks by
 # grid size) and on the 16-row kernel (mode 2): several query blocks, ragged last key tile and last row tile, one sub-tile only
 # (T = 20), an odd number of sub-tiles (T = 1000: 32 sub-tiles, T = 3000: 94, T = 257: 9), a late deferred-max rescale.
