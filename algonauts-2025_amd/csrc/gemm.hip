@@ -1484,6 +1484,17 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   return 0;
 }
 
+// the schedule itself, for inspection (tests/test_abi_and_host.py replays the kernel's decode on the host and checks that every K-step of
+// every tile is covered exactly once): out = {tiles_dp, rem_units, q, workers, second_worker[0 .. 255]}; returns the grid size
+extern "C" int tribe_gemm_stream_k_plan(int32_t tiles, int32_t nk, int32_t* out) {
+  TRIBE_REQUIRE(tiles > 0 && nk > 0 && out != nullptr, "tribe_gemm_stream_k_plan: bad argument");
+  SkSched sk;
+  const unsigned grid = tribe_gemm_detail::plan_stream_k(tiles, nk, &sk);
+  out[0] = sk.tiles_dp; out[1] = sk.rem_units; out[2] = sk.q; out[3] = sk.workers;
+  for (int i = 0; i < 256; ++i) out[4 + i] = sk.second_worker[i];
+  return (int)grid;
+}
+
 extern "C" int64_t tribe_gemm_stream_k_workspace_bytes(const tribe_gemm_desc* d) {
   TRIBE_REQUIRE(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0 && d->K % BK == 0, "tribe_gemm_stream_k_workspace_bytes: bad descriptor");
   if (!d->trans_ab || !d->stream_k || d->batch1 * d->batch0 != 1) return 0;

@@ -193,6 +193,7 @@ SIGNATURES = {
     "tribe_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "tribe_gemm_sumsq_slots": (C.c_int, [C.POINTER(GemmDesc)]),
     "tribe_gemm_stream_k_workspace_bytes": (i64, [C.POINTER(GemmDesc)]),
+    "tribe_gemm_stream_k_plan": (C.c_int, [i32, i32, C.POINTER(i32)]),
     "tribe_prof_begin": (C.c_int, [i32]),
     "tribe_prof_end": (C.c_int, [i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "tribe_pack_weight_bf16": (C.c_int, [vp, i64, i64, i64, vp, i64, i64, vp]),

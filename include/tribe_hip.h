@@ -126,6 +126,10 @@ int tribe_gemm_bf16(const tribe_gemm_desc* desc, void* stream);
 int tribe_gemm_sumsq_slots(const tribe_gemm_desc* desc);
 /* bytes of desc->stream_k_ws this launch needs: 0 when it would not be split (stream_k clear, not trans_ab, or no partial round worth cutting) */
 int64_t tribe_gemm_stream_k_workspace_bytes(const tribe_gemm_desc* desc);
+/* The stream-K schedule of a launch with `tiles` output tiles of `nk` K-steps on this device (host-only, for inspection and tests):
+ * out[0..3] = {tiles computed whole, K-steps in the split region, K-steps per run, runs}, out[4 .. 259] = the order in which the runs' second
+ * parts are queued.  Returns the grid size (== tiles when nothing is split, and then out[0] >= tiles). */
+int tribe_gemm_stream_k_plan(int32_t tiles, int32_t nk, int32_t* out);
 /* scale[m] = g[0] * gain_scale / max(sqrt(sum_p partial[m, p]), eps): the ScaleNorm factor from the partial sums of squares a
  * GEMM epilogue left in row_sumsq (partial f32 [rows, n_partial], row-major). */
 int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64_t n_partial, const float* g, float gain_scale, float eps,

@@ -73,6 +73,60 @@ def test_argument_errors_do_not_need_a_gpu():
     assert handle.tribe_attention_workspace_bytes(4, 1024, 8, 384) > 0
 
 
+@pytest.mark.parametrize("tiles,nk", [(576, 256), (64, 256), (120, 136), (6, 344), (272, 128), (144, 256), (432, 256), (4, 2), (300, 9), (257, 64)])
+def test_stream_k_schedule_covers_every_k_step_once(tiles, nk):
+    """tribe_gemm_stream_k_plan is the schedule the weight-gradient kernel decodes from blockIdx (csrc/gemm.hip, SkSched).  The decode is
+    replayed here: every K-step of every tile must be covered exactly once, whole tiles by one workgroup, split tiles by parts that the
+    reduce kernel finds under the slots it computes, and the second parts must be queued longest first."""
+    from tribe_hip import _lib
+
+    out = (ctypes.c_int32 * 260)()
+    grid = _lib.lib().tribe_gemm_stream_k_plan(tiles, nk, out)
+    tiles_dp, rem_units, q, workers = out[0], out[1], out[2], out[3]
+    second_worker = list(out[4:260])
+    if grid == tiles:                      # nothing split
+        assert tiles_dp >= tiles
+        return
+    assert 0 <= tiles_dp < tiles and tiles_dp % workers == 0 and rem_units == (tiles - tiles_dp) * nk and q * workers >= rem_units
+    assert (tiles - tiles_dp) * 2 <= workers and q >= 8
+    cover = {t: [0] * nk for t in range(tiles)}
+    slots = {}                             # (tile, first K-step) -> workspace slot of a partial workgroup
+    second_lengths = []
+    for b in range(grid):
+        if b < tiles_dp:
+            tile, k0, n = b, 0, nk
+        else:
+            sidx = b - tiles_dp
+            second = sidx >= workers
+            w = second_worker[sidx - workers] if second else sidx
+            u0 = w * q
+            if u0 >= rem_units:
+                continue
+            run = min(q, rem_units - u0)
+            t_loc, x = divmod(u0, nk)
+            first_len = min(run, nk - x)
+            if second and first_len >= run:
+                continue
+            tile, k0, n = tiles_dp + t_loc + int(second), (0 if second else x), (run - first_len if second else first_len)
+            if second:
+                second_lengths.append(n)
+            if n != nk:
+                slots[(tile, k0)] = 2 * w + int(second)
+        for k in range(k0, k0 + n):
+            cover[tile][k] += 1
+    assert all(c == 1 for row in cover.values() for c in row)
+    assert second_lengths == sorted(second_lengths, reverse=True)
+    # the reduce kernel's view: the parts of split tile t_loc are the runs w_lo .. w_hi, slot 2 w + (run began in the previous tile)
+    for t_loc in range(tiles - tiles_dp):
+        u_lo, u_hi = t_loc * nk, t_loc * nk + nk - 1
+        w_lo, w_hi = u_lo // q, u_hi // q
+        if w_lo == w_hi:
+            assert not any(t == tiles_dp + t_loc for t, _ in slots)
+            continue
+        found = sorted(2 * w + int(w * q < u_lo) for w in range(w_lo, w_hi + 1))
+        assert found == sorted(v for (t, _), v in slots.items() if t == tiles_dp + t_loc)
+
+
 def test_host_surface_matches_reference_names():
     from algonauts2025.model import FmriEncoder, FmriEncoderConfig
     from algonauts2025.pl_module import BrainModule
