@@ -347,10 +347,9 @@ def run_rank(args) -> None:
         by_kernel = _role_table(prof)
         dom = max(prof, key=lambda k: prof[k]["ms"])
         gemm_ms = sum(r["ms"] for r in prof.values()) / args.steps
-        # kernel symbol behind the dominant role at this batch: QKV / FF1 run the one-wave-per-SIMD 256 x 256 kernel, the other GEMM
-        # roles the 8-wave one (csrc/gemm.hip: gemm_plan)
-        dom_name = ("attn_fwd_wide384_kernel" if dom == "attention" else
-                    f"gemm_nt_4w256<{dom}>" if dom in ("qkv", "ff1") else f"gemm_nt_256x256x64<{dom}>")
+        # kernel symbol behind the dominant role at this batch: every GEMM role runs the 8-wave 256 x 256 kernel by default (csrc/gemm.hip:
+        # gemm_plan; the one-wave-per-SIMD gemm_nt_4w256 is tile_hint 5) -- rocprof shows it as gemm_nt_256x256x64<out_bf16, role, 0, 4>
+        dom_name = "attn_fwd_wide384_kernel" if dom == "attention" else f"gemm_nt_256x256x64<{dom}>"
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": by_kernel[dom]["achieved_tflops"],
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": by_kernel[dom]["frac"], "traffic": None,
                     "traffic_source": None,
