@@ -141,7 +141,7 @@ extern "C" int tribe_attention_fwd(const uint16_t* qkv, int64_t B, int64_t T, in
 namespace {
 struct EncPlan {
   int64_t M, inner;
-  size_t xn_bytes, big_bytes, attn_bytes, norm_bytes;
+  size_t xn_bytes, big_bytes, attn_bytes, norm_bytes, split_bytes;
   bool fuse_norm;   // ScaleNorm folded into the GEMMs either side of it (needs whole 256-column tiles)
 };
 inline EncPlan enc_plan(const tribe_encoder_desc* d) {
@@ -154,6 +154,10 @@ inline EncPlan enc_plan(const tribe_encoder_desc* d) {
   p.attn_bytes = align256(tribe_attention_workspace_bytes(d->B, d->T, d->heads, d->dim_head));
   p.fuse_norm = d->dim % 256 == 0 && p.inner % 256 == 0 && d->ff_inner % 256 == 0;
   p.norm_bytes = p.fuse_norm ? align256((size_t)p.M * (d->dim / 32 + 1) * 4) : 0;   // partial sums of squares (<= dim / 32 slots per row, by the producer's tile) + the row factors
+  // few rows (BASELINE config 1: M = 128): the four GEMMs of a layer are well under one round of tiles and run split over K
+  // (tribe_gemm_desc.stream_k) -- up to 8 f32 shares of the widest output
+  const int64_t widest = 3 * p.inner > d->ff_inner ? (3 * p.inner > d->dim ? 3 * p.inner : d->dim) : (d->ff_inner > d->dim ? d->ff_inner : d->dim);
+  p.split_bytes = p.M <= 512 ? align256((size_t)8 * p.M * widest * 4) : 0;
   return p;
 }
 inline int enc_validate(const tribe_encoder_desc* d) {
@@ -172,7 +176,7 @@ inline int enc_validate(const tribe_encoder_desc* d) {
 extern "C" size_t tribe_encoder_workspace_bytes(const tribe_encoder_desc* d) {
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   const EncPlan p = enc_plan(d);
-  return p.xn_bytes + p.big_bytes + p.attn_bytes + p.norm_bytes;
+  return p.xn_bytes + p.big_bytes + p.attn_bytes + p.norm_bytes + p.split_bytes;
 }
 
 extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y, int32_t y_dtype, void* workspace,
@@ -193,6 +197,15 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
   void* attn_ws = (char*)workspace + p.xn_bytes + p.big_bytes;
   float* ssq = (float*)((char*)workspace + p.xn_bytes + p.big_bytes + p.attn_bytes);   // [M, n_part] partial sums of squares
   float* rowf = ssq + (size_t)M * (dim / 32);                                          // [M] ScaleNorm factors
+  void* split_ws = (char*)workspace + p.xn_bytes + p.big_bytes + p.attn_bytes + p.norm_bytes;
+  // a GEMM of a small batch may run split over K: hand it the workspace when the launcher says it would use one
+  auto allow_split = [&](tribe_gemm_desc& g) {
+    if (p.split_bytes == 0) return;
+    g.stream_k = 1;
+    const int64_t need = tribe_gemm_stream_k_workspace_bytes(&g);
+    if (need > 0 && (size_t)need <= p.split_bytes) { g.stream_k_ws = split_ws; g.stream_k_ws_bytes = (int64_t)p.split_bytes; }
+    else g.stream_k = 0;
+  };
   int64_t n_part = dim / 64;   // slots per row the LAST producer wrote (one per wave column group of its tile: tribe_gemm_sumsq_slots)
   const float scale = 1.0f / sqrtf((float)d->dim_head);
   // With whole 256-column tiles the pre-norms are folded into the GEMMs: the GEMM that writes x also leaves bf16(x) in `xn` and
@@ -219,6 +232,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.A = xn; g.lda = dim; g.B = L.w_qkv; g.ldb = dim;
     g.C = qkv; g.ldc = 3 * inner; g.c_dtype = TRIBE_BF16;
     g.role = TRIBE_ROLE_QKV;
+    allow_split(g);
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     // q heads and k heads are adjacent in the fused row.  The DH = 384 attention kernel rotates Q while it loads its Q fragments
@@ -248,6 +262,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
       TRIBE_REQUIRE(n_part > 0 && n_part <= dim / 32, "tribe_encoder_fwd: unexpected row_sumsq slot count %lld", (long long)n_part);
       g.ld_row_sumsq = n_part;
     }
+    allow_split(g);
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     // ---- feed-forward block: x = W2 gelu(W1 norm(x) + b1) + b2 + x * residual_scale ----
@@ -264,6 +279,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
     g.C = hbuf; g.ldc = d->ff_inner; g.c_dtype = TRIBE_BF16;
     g.bias = L.b_ff1; g.bias_mode = TRIBE_BIAS_COL; g.act = TRIBE_ACT_GELU;
     g.role = TRIBE_ROLE_FF1;
+    allow_split(g);
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
     g = gemm_zero();
@@ -280,6 +296,7 @@ extern "C" int tribe_encoder_fwd(const tribe_encoder_desc* d, float* x, void* y,
       TRIBE_REQUIRE(n_part > 0 && n_part <= dim / 32, "tribe_encoder_fwd: unexpected row_sumsq slot count %lld", (long long)n_part);
       g.ld_row_sumsq = n_part;
     }
+    allow_split(g);
     rc = tribe_gemm_bf16(&g, stream);
     if (rc) return rc;
   }

@@ -584,8 +584,11 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
 constexpr int SMEM_BYTES = STAGES * STAGE_BYTES;  // 128 KiB
 }  // namespace ring
 
+// Split-K (round 3, desc.stream_k on an NT launch): grids far below one round of tiles -- M = 128 rows, BASELINE config 1: FF2 is 24 tiles of
+// 192 K-steps -- run `splits` workgroups per tile, each over a contiguous share of the K-steps; they store their raw accumulators to
+// ws[split][M][N] (f32) and splitk_epilogue_kernel, launched behind, sums the shares in order and applies the launch's epilogue operators.
 template <int OUT_BF16, int ROLE>
-__global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc g, int tiles_m, int tiles_n, int splits, float* ws) {
   using namespace ring;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -593,8 +596,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
   const int wr = wave >> 1, wc = wave & 1;                    // 4 x 2 waves of 32 x 64
 
+  const int ntile = tiles_m * tiles_n;
+  const int split = splits > 1 ? (int)blockIdx.x / ntile : 0;
   int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  tile_coords((int)blockIdx.x - split * ntile, tiles_m, tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int64_t z = blockIdx.y;
@@ -617,9 +622,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
     a_src[p] = A + gr * g.lda + schunk * 8;
     b_src[p] = B + gc * g.ldb + schunk * 8;
   }
+  const int nk_all = (int)(g.K / BK);
+  const int k_first = splits > 1 ? (int)((int64_t)split * nk_all / splits) : 0;
+  const int nk = splits > 1 ? (int)((int64_t)(split + 1) * nk_all / splits) - k_first : nk_all;
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE_BYTES + wave * 1024;
-    const int koff = kt * BK;
+    const int koff = (k_first + kt) * BK;
     __builtin_amdgcn_global_load_lds((gptr_t)(a_src[0] + koff), (lptr_t)(base), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(b_src[0] + koff), (lptr_t)(base + TILE_BYTES), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(a_src[1] + koff), (lptr_t)(base + 8192), 16, 0, 0);
@@ -637,7 +645,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
   const int a_rd = (wr * 32 + frow) * 128;                 // + i * 2048 + coff
   const int b_rd = TILE_BYTES + (wc * 64 + frow) * 128;    // + j * 2048 + coff
 
-  const int nk = (int)(g.K / BK);
   if (0 < nk) stage(0, 0);
   if (1 < nk) stage(1, 1);
   if (2 < nk) stage(2, 2);
@@ -696,6 +703,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
   }
   __builtin_amdgcn_s_barrier();   // the staging buffers become the epilogue's scratch: every wave is past its last fragment read
 
+  if (splits > 1) {   // this workgroup's share of the reduction, raw: [split][M][N] f32, four consecutive columns of a row per lane
+    float* wsp = ws + (int64_t)split * g.M * g.N;
+    static_for<8>([&](auto t) {
+      constexpr int i = decltype(t)::value / 4, j = decltype(t)::value % 4;
+      float v[4];
+      quad_transpose(acc[i][j], 1.0f, lane, v);
+      const int64_t m = m0 + wr * 32 + i * 16 + ((lane >> 4) << 2) + (lane & 3), n = n0 + wc * 64 + j * 16 + (((lane & 15) >> 2) << 2);
+      if (m < g.M && n < g.N) *(float4*)(wsp + m * g.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+    });
+    return;
+  }
   const EpiCtx ctx = make_epi_ctx(g, b1, b0, b1g);
   if (epilogue_fast_ok<(ROLE == TRIBE_ROLE_EXT)>(g, ctx) && n0 + BN <= g.N) {
     epilogue_fast<OUT_BF16, 2, 4, (ROLE == TRIBE_ROLE_EXT)>(g, ctx, acc, m0 + wr * 32, n0 + wc * 64, lane, smem + wave * 8192);
@@ -707,6 +725,72 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring128(const tribe_gemm_desc 
   });
 }
 
+
+// Second launch of a split-K GEMM: thread = four consecutive columns of one row; sums the shares in split order (deterministic) and applies
+// the operators of the wait-free epilogue in its order: alpha, row_scale, row / column bias, GELU (the bf16 / f32 forms of the GEMM epilogues),
+// scaled residual or periodic row add, store, bf16 copy, row sums of squares (slot n / 64: 16 consecutive lanes hold 64 columns of a row).
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const tribe_gemm_desc g, int splits, const float* __restrict__ ws) {
+  const int64_t n4 = g.N >> 2, total = g.M * n4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < total;
+  const int64_t id = live ? idx : total - 1;
+  const int64_t m = id / n4, n = (id - m * n4) << 2;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sp = 0; sp < splits; ++sp) {
+    const float4 p = *(const float4*)(ws + ((int64_t)sp * g.M + m) * g.N + n);
+    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+  }
+  float v[4] = {acc.x * g.alpha, acc.y * g.alpha, acc.z * g.alpha, acc.w * g.alpha};
+  if (g.row_scale) {
+    const float sc = g.row_scale[m];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] *= sc;
+  }
+  if (g.bias_mode == TRIBE_BIAS_ROW) {
+    const float b = g.bias[m];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += b;
+  } else if (g.bias_mode == TRIBE_BIAS_COL) {
+    const float4 b = *(const float4*)(g.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (g.act == TRIBE_ACT_GELU) {
+    if (OUT_BF16) {
+      const f32x2_t lo = gelu_poly2(f32x2_t{v[0], v[1]}), hi = gelu_poly2(f32x2_t{v[2], v[3]});
+      v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = gelu_erf(v[k]);
+    }
+  }
+  if (g.res) {
+    const float4 r = *(const float4*)(g.res + m * g.ldres + n);
+    if (g.res_scale) {
+      const float4 sc = *(const float4*)(g.res_scale + n);
+      v[0] += r.x * sc.x; v[1] += r.y * sc.y; v[2] += r.z * sc.z; v[3] += r.w * sc.w;
+    } else {
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+  } else if (g.rowadd) {
+    const float4 r = *(const float4*)(g.rowadd + (m % g.rowadd_period) * g.ld_rowadd + n);
+    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+  }
+  u16x4_t o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = f32_to_bf16(v[k]);
+  if (OUT_BF16) {
+    if (live) *(u16x4_t*)((unsigned short*)g.C + m * g.ldc + n) = o;
+  } else {
+    if (live) *(float4*)((float*)g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    if (g.c_bf16 && live) *(u16x4_t*)(g.c_bf16 + m * g.ld_c_bf16 + n) = o;
+    if (g.row_sumsq) {   // (the planner guarantees N % 64 == 0: a 16-lane group never straddles two rows)
+      float t = live ? v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3] : 0.f;
+      t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+      if (live && (threadIdx.x & 15) == 0) g.row_sumsq[m * g.ld_row_sumsq + (n >> 6)] = t;
+    }
+  }
+}
 
 // =============================================================================================
 // 256 x 256 x 64, ONE wave per SIMD (round 3): 4 waves, 128 x 128 per wave, accumulators in 256 AGPRs
@@ -1083,7 +1167,8 @@ enum { KIND_SMALL = 0, KIND_BIG = 1, KIND_RING = 2, KIND_BIG4W = 3 };
 void launch_big4(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_big4_tn(int bf, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n, const SkSched& sk);
 void launch_big3(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
-void launch_ring(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
+void launch_ring(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n, int splits, float* ws);
+void launch_splitk_epilogue(int bf, hipStream_t s, const tribe_gemm_desc* d, int splits, const float* ws);
 void launch_4w(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 void launch_small(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n);
 
@@ -1126,8 +1211,19 @@ TRIBE_GEMM_TABLE(launch_big3)
 #endif
 #if TRIBE_GEMM_HAS_PART(2)
 #define TRIBE_GEMM_CASE_launch_ring(idx, bf, role) \
-  case idx: launch_k<gemm_nt_ring128<bf, role>, 512, ring::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
-TRIBE_GEMM_TABLE(launch_ring)
+  case idx: launch_k<gemm_nt_ring128<bf, role>, 512, ring::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n, splits, ws); break;
+void launch_ring(int pair, dim3 grid, hipStream_t s, const tribe_gemm_desc* d, int tiles_m, int tiles_n, int splits, float* ws) {
+  switch (pair) {
+    TRIBE_GEMM_PAIRS(TRIBE_GEMM_CASE_launch_ring)
+    default: break;
+  }
+}
+void launch_splitk_epilogue(int bf, hipStream_t s, const tribe_gemm_desc* d, int splits, const float* ws) {
+  const int64_t threads = d->M * (d->N / 4);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (bf) hipLaunchKernelGGL(splitk_epilogue_kernel<1>, grid, dim3(256), 0, s, *d, splits, ws);
+  else hipLaunchKernelGGL(splitk_epilogue_kernel<0>, grid, dim3(256), 0, s, *d, splits, ws);
+}
 #define TRIBE_GEMM_CASE_launch_small(idx, bf, role) \
   case idx: launch_k<gemm_nt_128x128x64<bf, role>, 256, small::SMEM_BYTES>(grid, s, d, tiles_m, tiles_n); break;
 TRIBE_GEMM_TABLE(launch_small)
@@ -1257,7 +1353,7 @@ extern "C" int tribe_rownorm_scale_fwd(const float* partial, int64_t rows, int64
 #endif
 namespace tribe_gemm_detail {
 // Which kernel and tile a launch gets.  sumsq_cols = columns per row_sumsq slot (one slot per wave column group).
-struct GemmPlan { int kind, bm, bn, sumsq_cols; };
+struct GemmPlan { int kind, bm, bn, sumsq_cols; int splits = 1; };
 // true when the descriptor carries exactly the operator set epilogue_w4 compiles for its role (and the alignments its vector accesses need)
 static bool w4_role_ok(const tribe_gemm_desc* d) {
   const bool res_role = d->role == TRIBE_ROLE_OUT_PROJ || d->role == TRIBE_ROLE_FF2;
@@ -1299,7 +1395,21 @@ static GemmPlan gemm_plan(const tribe_gemm_desc* d) {
     // one workgroup per CU or fewer: the ring kernel (three K-tiles in flight); more: the double-buffered kernel, whose two or three
     // co-resident workgroups per CU cover for each other
     const bool ring = d->tile_hint == 3 || (d->tile_hint != 1 && t128 <= 256 && d->K >= 256);
-    return {ring ? KIND_RING : KIND_SMALL, 128, 128, 64};
+    GemmPlan plan{ring ? KIND_RING : KIND_SMALL, 128, 128, 64};
+    // split-K (desc.stream_k): a grid of at most half a round whose tiles have K-steps to share out -- as many workgroups per tile as fit one
+    // round, at least 8 K-steps each, at most 8 shares; operators the second launch knows, 16-byte accessible operands
+    if (ring && d->stream_k && nz == 1 && !d->gather1 && !d->gadd && !d->aux && (d->act == TRIBE_ACT_NONE || d->act == TRIBE_ACT_GELU) &&
+        !(d->res && d->rowadd) && d->N % 4 == 0 && (!d->row_sumsq || d->N % 64 == 0) && d->ldc % 4 == 0 && ((uintptr_t)d->C % 16) == 0 &&
+        (d->bias_mode != TRIBE_BIAS_COL || ((uintptr_t)d->bias % 16) == 0) && (!d->res || (d->ldres % 4 == 0 && ((uintptr_t)d->res % 16) == 0)) &&
+        (!d->res_scale || ((uintptr_t)d->res_scale % 16) == 0) && (!d->rowadd || (d->ld_rowadd % 4 == 0 && ((uintptr_t)d->rowadd % 16) == 0)) &&
+        (!d->c_bf16 || (d->ld_c_bf16 % 4 == 0 && ((uintptr_t)d->c_bf16 % 8) == 0))) {
+      const int64_t nk = d->K / BK;
+      int64_t sp = 256 / t128;
+      if (sp > nk / 8) sp = nk / 8;
+      if (sp > 8) sp = 8;
+      if (sp >= 2) plan.splits = (int)sp;
+    }
+    return plan;
   }
   // Tile quantisation on 256 CUs: a grid of 256 x 192 tiles when that cuts the rounds' worth of work (BASELINE config at B = 4, M = 4096:
   // QKV 576 -> 768 tiles = 3 rounds of 3/4-size tiles instead of 3 of full size; out-proj / FF2 192 -> 256 tiles: the whole chip
@@ -1477,7 +1587,15 @@ extern "C" int tribe_gemm_bf16(const tribe_gemm_desc* d, void* stream) {
   if (plan.kind == KIND_BIG4W) launch_4w(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
   else if (plan.kind == KIND_BIG && plan.bn == 192) launch_big3(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
   else if (plan.kind == KIND_BIG) launch_big4(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
-  else if (plan.kind == KIND_RING) launch_ring(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
+  else if (plan.kind == KIND_RING && plan.splits > 1) {
+    const int64_t need = (int64_t)plan.splits * d->M * d->N * 4;
+    TRIBE_REQUIRE(d->stream_k_ws && d->stream_k_ws_bytes >= need && ((uintptr_t)d->stream_k_ws % 16) == 0,
+                  "tribe_gemm_bf16: this launch is split over K: stream_k_ws must hold %lld bytes (tribe_gemm_stream_k_workspace_bytes)", (long long)need);
+    TRIBE_REQUIRE(tiles_m * tiles_n * plan.splits < (1ll << 31) && d->M * (d->N / 4) < (1ll << 39), "tribe_gemm_bf16: grid too large");
+    grid.x = (unsigned)(tiles_m * tiles_n * plan.splits);
+    launch_ring(pair, grid, s, d, (int)tiles_m, (int)tiles_n, plan.splits, (float*)d->stream_k_ws);
+    launch_splitk_epilogue(bf ? 1 : 0, s, d, plan.splits, (const float*)d->stream_k_ws);
+  } else if (plan.kind == KIND_RING) launch_ring(pair, grid, s, d, (int)tiles_m, (int)tiles_n, 1, nullptr);
   else launch_small(pair, grid, s, d, (int)tiles_m, (int)tiles_n);
   prof_after(slot, s);
   TRIBE_LAUNCH_CHECK();
@@ -1497,7 +1615,11 @@ extern "C" int tribe_gemm_stream_k_plan(int32_t tiles, int32_t nk, int32_t* out)
 
 extern "C" int64_t tribe_gemm_stream_k_workspace_bytes(const tribe_gemm_desc* d) {
   TRIBE_REQUIRE(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0 && d->K % BK == 0, "tribe_gemm_stream_k_workspace_bytes: bad descriptor");
-  if (!d->trans_ab || !d->stream_k || d->batch1 * d->batch0 != 1) return 0;
+  if (!d->stream_k || d->batch1 * d->batch0 != 1) return 0;
+  if (!d->trans_ab) {   // NT form: split-K of a small grid (ring kernel)
+    const tribe_gemm_detail::GemmPlan plan = tribe_gemm_detail::gemm_plan(d);
+    return plan.splits > 1 ? (int64_t)plan.splits * d->M * d->N * 4 : 0;
+  }
   SkSched sk;
   const int tiles = (int)(((d->M + 255) / 256) * ((d->N + 255) / 256));
   if (tribe_gemm_detail::plan_stream_k(tiles, (int)(d->K / BK), &sk) == (unsigned)tiles) return 0;

@@ -65,8 +65,11 @@ def gemm_nt(
     out_dtype: torch.dtype = torch.float32, out: torch.Tensor | None = None,
     rowadd: torch.Tensor | None = None, rowadd_period: int = 0,
     gadd: torch.Tensor | None = None, gadd_index: torch.Tensor | None = None, gadd_div: int = 0, tile_hint: int = 0,
+    split_k: bool = False,
 ) -> torch.Tensor:
-    """out[..., m, n] = epi(alpha * sum_k a[..., m, k] * b[..., n, k]); a, b bf16 with equal leading batch dim (or 2-D)."""
+    """out[..., m, n] = epi(alpha * sum_k a[..., m, k] * b[..., n, k]); a, b bf16 with equal leading batch dim (or 2-D).
+    split_k: let the launcher share the reduction of a small grid out over several workgroups per tile (tribe_gemm_desc.stream_k);
+    gemm_nt.last_split tells whether it did."""
     _cuda(a, torch.bfloat16, "a")
     _cuda(b, torch.bfloat16, "b")
     if a.ndim == 2:
@@ -105,8 +108,19 @@ def gemm_nt(
         _cuda(gadd, torch.float32, "gadd")
         _cuda(gadd_index, torch.int64, "gadd_index")
         d.gadd, d.gadd_index, d.gadd_div, d.ld_gadd = gadd.data_ptr(), gadd_index.data_ptr(), gadd_div, gadd.shape[-1]
+    gemm_nt.last_split = False
+    if split_k:
+        d.stream_k = 1
+        nbytes = lib().tribe_gemm_stream_k_workspace_bytes(C.byref(d))
+        gemm_nt.last_split = nbytes > 0
+        if nbytes > 0:
+            ws = workspace(nbytes, a.device, tag="streamk")
+            d.stream_k_ws, d.stream_k_ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     check(lib().tribe_gemm_bf16(C.byref(d), _stream()), "tribe_gemm_bf16")
     return out
+
+
+gemm_nt.last_split = False
 
 
 def gemm_tn(at: torch.Tensor, bt: torch.Tensor, *, out_dtype: torch.dtype = torch.float32, alpha: float = 1.0,

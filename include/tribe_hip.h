@@ -111,11 +111,14 @@ typedef struct tribe_gemm_desc {
   float* row_sumsq; int64_t ld_row_sumsq;
   const float* row_scale;
   int64_t sBias0;          /* + b0 * sBias0 on the bias pointer (a ROW bias per (b1, b0) batch: the attention backward's -lse2 / -scale * D); 0 = none */
-  /* trans_ab only (the weight-gradient form, whose few output tiles rarely fill the chip: dW of a 3072 x 3072 layer is 144 tiles on 256 CUs):
-   * 1 = the launcher may cut the reduction of the last, partial round of tiles into equal runs over all CUs (stream-K).  Workgroups that hold
-   * part of a tile leave their accumulators in stream_k_ws; a second launch on the same stream sums the parts of each split tile in a fixed
-   * order (bit-reproducible) and writes C.  Plain f32 product only (no bias / activation / residual / batch).  The workspace must hold
-   * tribe_gemm_stream_k_workspace_bytes(desc) bytes (0 = this launch is not split), 16-byte aligned, and is free again when the launch is done. */
+  /* 1 = the launcher may share out the REDUCTION of a launch whose output tiles do not fill the chip over more workgroups; the parts travel
+   * through stream_k_ws and a second launch on the same stream sums them in a fixed order (bit-reproducible) and writes C.
+   *   trans_ab (the weight-gradient form: dW of a 3072 x 3072 layer is 144 tiles on 256 CUs): stream-K -- the tiles of the last, partial round
+   *     are cut into equal runs of K-steps over all CUs.  Plain f32 product only (no bias / activation / residual / batch).
+   *   otherwise (NT form): split-K of grids of at most half a round of 128 x 128 tiles (M = 128 rows: BASELINE config 1) -- 2..8 workgroups
+   *     per tile; the second launch applies alpha, row_scale, bias, GELU, the scaled residual or periodic row add, c_bf16 and row_sumsq.
+   * The workspace must hold tribe_gemm_stream_k_workspace_bytes(desc) bytes (0 = this launch is not split), 16-byte aligned, and is free
+   * again when the launch is done. */
   int32_t stream_k; int32_t reserved0;
   void* stream_k_ws; int64_t stream_k_ws_bytes;
 } tribe_gemm_desc;

@@ -458,6 +458,84 @@ def test_gemm_transposed_operands(ops, M, N, K):
         ops.gemm_tn(_dev(at[:, : M - 3].contiguous()).bfloat16(), _dev(bt).bfloat16())   # M not a multiple of 8
 
 
+# Split-K of small NT grids (tribe_gemm_desc.stream_k without trans_ab): the four GEMMs of an encoder layer at M = 128 rows (BASELINE config 1)
+# with their model epilogues -- QKV: row_scale -> bf16; FF1: row_scale + bias + GELU -> bf16; out-proj / FF2: [bias +] scaled f32 residual in
+# place + bf16 copy + row sums of squares -- against the same launch without the split; plain shapes through ops.gemm_nt (ragged M, rowadd).
+@pytest.mark.parametrize("role,M,N,K", [("qkv", 128, 9216, 3072), ("ff1", 128, 12288, 3072), ("out_proj", 128, 3072, 3072), ("ff2", 128, 3072, 12288),
+                                        ("ff2", 200, 768, 4096), ("qkv", 100, 1152, 1024)])
+def test_gemm_split_k_with_model_epilogues(ops, role, M, N, K):
+    import ctypes as C
+
+    from tribe_hip import _lib
+
+    g = torch.Generator().manual_seed(N + K)
+    a, b = _dev(torch.randn(M, K, generator=g)).bfloat16(), _dev(torch.randn(N, K, generator=g) / K**0.5).bfloat16()
+    bias, rs, scale = _dev(torch.randn(N, generator=g)), _dev(torch.rand(N, generator=g) + 0.5), _dev(torch.rand(M, generator=g) + 0.5)
+    x0 = _dev(torch.randn(M, N, generator=g))
+    res_role = role in ("out_proj", "ff2")
+    s = torch.cuda.current_stream().cuda_stream
+    got = {}
+    for split in (False, True):
+        x = x0.clone()
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        ssq = torch.full((M, N // 32 + 1), float("nan"), device="cuda")
+        d = _lib.GemmDesc()
+        d.M, d.N, d.K, d.batch1, d.batch0 = M, N, K, 1, 1
+        d.A, d.lda, d.B, d.ldb, d.alpha = a.data_ptr(), K, b.data_ptr(), K, 1.0
+        d.role = _lib.ROLES.index(role)
+        if res_role:
+            d.C, d.ldc, d.c_dtype, d.res, d.ldres, d.res_scale = x.data_ptr(), N, _lib.F32, x.data_ptr(), N, rs.data_ptr()
+            d.c_bf16, d.ld_c_bf16, d.row_sumsq = out.data_ptr(), N, ssq.data_ptr()
+            if role == "ff2":
+                d.bias, d.bias_mode = bias.data_ptr(), _lib.BIAS_COL
+        else:
+            d.C, d.ldc, d.c_dtype, d.row_scale = out.data_ptr(), N, _lib.BF16, scale.data_ptr()
+            if role == "ff1":
+                d.bias, d.bias_mode, d.act = bias.data_ptr(), _lib.BIAS_COL, _lib.ACT_GELU
+        nbytes = 0
+        if split:
+            d.stream_k = 1
+            nbytes = _lib.lib().tribe_gemm_stream_k_workspace_bytes(C.byref(d))
+            assert nbytes > 0, "these shapes are far below one round of tiles: the planner must split them"
+            ws = ops.workspace(nbytes, x.device, tag="streamk")
+            d.stream_k_ws, d.stream_k_ws_bytes = ws.data_ptr(), ws.numel()
+        slots = 0
+        if res_role:
+            slots = _lib.lib().tribe_gemm_sumsq_slots(C.byref(d))
+            d.ld_row_sumsq = slots
+        _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(d), s), "tribe_gemm_bf16")
+        got[split] = (x.cpu(), out.float().cpu(), ssq.flatten()[: M * slots].view(M, slots).sum(1).cpu() if res_role else None)
+    if res_role:
+        torch.testing.assert_close(got[True][0], got[False][0], rtol=2e-5, atol=2e-5 * K**0.5)
+        assert torch.equal(got[True][1], got[True][0].bfloat16().float())                       # the bf16 copy is the copy of what was stored
+        torch.testing.assert_close(got[True][2], (got[True][0].double() ** 2).sum(1).float(), rtol=1e-5, atol=1e-3)
+    else:
+        torch.testing.assert_close(got[True][1], got[False][1], rtol=2**-7, atol=2e-3)       # bf16 outputs: one rounding step apart at most
+    if split and not res_role:
+        with pytest.raises(ValueError, match="split over K"):                                   # split planned, no workspace handed over
+            d.stream_k_ws = None
+            _lib.check(_lib.lib().tribe_gemm_bf16(C.byref(d), s), "tribe_gemm_bf16")
+
+
+def test_gemm_split_k_plain_shapes(ops):
+    g = torch.Generator().manual_seed(4)
+    for M, N, K, kw in [(77, 1000, 4096, {}), (128, 1024, 4096, {"rowadd": True}), (60, 256, 8192, {"out_dtype": torch.bfloat16, "bias": True, "act": "gelu"})]:
+        a, b = _dev(torch.randn(M, K, generator=g)).bfloat16(), _dev(torch.randn(N, K, generator=g) / K**0.5).bfloat16()
+        args = {"out_dtype": kw.get("out_dtype", torch.float32), "act": kw.get("act")}
+        if kw.get("bias"):
+            args["bias"] = _dev(torch.randn(N, generator=g))
+        if kw.get("rowadd"):
+            args["rowadd"], args["rowadd_period"] = _dev(torch.randn(32, N, generator=g)), 32
+        whole = ops.gemm_nt(a, b, **args)
+        split = ops.gemm_nt(a, b, split_k=True, **args)
+        assert ops.gemm_nt.last_split
+        tol = dict(rtol=2**-7, atol=2e-3) if args["out_dtype"] == torch.bfloat16 else dict(rtol=2e-5, atol=2e-5 * K**0.5)
+        torch.testing.assert_close(split.float(), whole.float(), **tol)
+        assert torch.equal(ops.gemm_nt(a, b, split_k=True, **args), split)       # shares summed in a fixed order
+    big = ops.gemm_nt(_dev(torch.randn(4096, 256, generator=g)).bfloat16(), _dev(torch.randn(3072, 256, generator=g)).bfloat16(), split_k=True)
+    assert not ops.gemm_nt.last_split and big.shape == (4096, 3072)
+
+
 # Stream-K schedule of the transposed-operand GEMM (tribe_gemm_desc.stream_k): shapes whose tile count leaves at most half a round on 256 CUs --
 # 6 tiles (ragged M / N), 120 tiles of 136 K-steps (runs of 64 K-steps: most cross a tile boundary), 272 tiles (one whole round stored plainly
 # + 16 tiles cut into 256 runs) -- and two that are left alone (4 tiles x 2 K-steps; 144 tiles = more than half a round).
