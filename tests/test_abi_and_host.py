@@ -127,6 +127,30 @@ def test_stream_k_schedule_covers_every_k_step_once(tiles, nk):
         assert found == sorted(v for (t, _), v in slots.items() if t == tiles_dp + t_loc)
 
 
+def test_split_planner_leaves_the_headline_shapes_whole():
+    """tribe_gemm_stream_k_workspace_bytes is the planner's answer without a launch: the encoder GEMMs of BASELINE config 1 (M = 128 rows) are
+    split over K (2-8 workgroups per 128 x 128 tile, >= 8 K-steps each, at most one round), those of the B = 4 and B = 64 batches never are;
+    weight gradients take the stream-K schedule only for remainders up to half a round."""
+    from tribe_hip import _lib
+
+    def nbytes(M, N, K, trans_ab=0, **kw):
+        d = _lib.GemmDesc()
+        d.M, d.N, d.K, d.batch1, d.batch0, d.alpha, d.stream_k, d.trans_ab = M, N, K, 1, 1, 1.0, 1, trans_ab
+        d.c_dtype = kw.get("c_dtype", _lib.F32)
+        d.act = kw.get("act", _lib.ACT_NONE)
+        return _lib.lib().tribe_gemm_stream_k_workspace_bytes(ctypes.byref(d))
+
+    for (N, K), splits in {(9216, 3072): 3, (3072, 3072): 6, (12288, 3072): 2, (3072, 12288): 8}.items():
+        assert nbytes(128, N, K) == splits * 128 * N * 4, (N, K)
+        for M in (4096, 65536):
+            assert nbytes(M, N, K) == 0, (M, N, K)
+    assert nbytes(128, 3072, 3072, act=_lib.ACT_SWIGLU) == 0          # an operator the second launch does not know
+    assert nbytes(128, 3072, 192) == 0                                # K too short to share out (and below the ring kernel's K)
+    slot = 2 * 256 * 256 * 256 * 4                                    # stream-K: two 256 x 256 f32 slots per worker
+    assert nbytes(12288, 3072, 16384, trans_ab=1) == slot and nbytes(1024, 4096, 16384, trans_ab=1) == slot
+    assert nbytes(9216, 3072, 16384, trans_ab=1) == 0 and nbytes(3072, 3072, 16384, trans_ab=1) == 0
+
+
 def test_host_surface_matches_reference_names():
     from algonauts2025.model import FmriEncoder, FmriEncoderConfig
     from algonauts2025.pl_module import BrainModule
