@@ -51,7 +51,9 @@ for role, M, N, K in SHAPES:
                 d.bias, d.bias_mode, d.act = bias.data_ptr(), _lib.BIAS_COL, _lib.ACT_GELU
         return d
 
-    arms = [(n, h, hint) for n, h in libs.items() for hint in ((2, 5) if n == next(iter(libs)) else (5,))]
+    import os
+    arms = ([(n, h, 2) for n, h in libs.items()] if os.environ.get("LAB_HINT2_ONLY") else   # A/B of two builds of the 8-wave kernel
+            [(n, h, hint) for n, h in libs.items() for hint in ((2, 5) if n == next(iter(libs)) else (5,))])
     times = {(n, hint): [] for n, _, hint in arms}
     reps = 3 if M > 10000 else 20
     for rnd in range(5):
