@@ -1,6 +1,6 @@
 """The two epilogue GEMMs of the attention backward (P = exp2(scale log2e q.k - lse2), dS = (scale dO.v - scale D) * P), batched over
 (sequence, head) = 128 at B = 16, T = 1024, d = 384 -- against the same batched product with a plain bf16 / f32 store and on the other
-tile kernels (tile_hint), to see what a 6-K-step tile pays for.  Usage: python scripts/attn_bwd_gemm_lab.py"""
+tile kernels (tile_hint), to see what a 6-K-step tile pays for.  Usage: python scripts/attn_bwd_gemm_lab.py [T]"""
 import ctypes as C
 import statistics
 import sys
@@ -13,14 +13,15 @@ import torch  # noqa: E402
 from tribe_hip import _lib  # noqa: E402
 
 dev = torch.device("cuda")
-nb, h, T, d = 16, 8, 1024, 384
+nb, h, T, d = 16, 8, (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 384
+Tp = (T + 63) // 64 * 64   # score buffers are padded to 64 columns as in modeling_utils/autograd.py
 inner, ld = h * d, 3 * h * d
 qkv = torch.randn(nb * T, ld, device=dev).bfloat16()
 dout = torch.randn(nb * T, inner, device=dev).bfloat16()
 bias = torch.randn(nb, h, T, device=dev)
-P = torch.empty(nb * h, T, T, dtype=torch.bfloat16, device=dev)
+P = torch.zeros(nb * h, T, Tp, dtype=torch.bfloat16, device=dev)
 dS = torch.empty_like(P)
-F = torch.empty(nb * h, T, T, dtype=torch.float32, device=dev)
+F = torch.empty(nb * h, T, Tp, dtype=torch.float32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 lib = _lib.lib()
 
@@ -32,12 +33,12 @@ def desc(kind, hint):
     g.A = dout.data_ptr() if kind == "ds" else qkv.data_ptr()
     g.B, g.ldb, g.sB1, g.sB0 = qkv.data_ptr() + 2 * (2 * inner if kind == "ds" else inner), ld, T * ld, d
     out = F if kind == "f32" else (dS if kind == "ds" else P)
-    g.C, g.ldc, g.sC1, g.sC0, g.c_dtype = out.data_ptr(), T, h * T * T, T * T, (_lib.F32 if kind == "f32" else _lib.BF16)
+    g.C, g.ldc, g.sC1, g.sC0, g.c_dtype = out.data_ptr(), Tp, h * T * Tp, T * Tp, (_lib.F32 if kind == "f32" else _lib.BF16)
     if kind in ("p", "ds"):
         g.bias, g.bias_mode, g.sBias1, g.sBias0 = bias.data_ptr(), _lib.BIAS_ROW, h * T, T
         g.act = _lib.ACT_EXP2 if kind == "p" else _lib.ACT_MUL_AUX
     if kind == "ds":
-        g.aux, g.ld_aux = P.data_ptr(), T
+        g.aux, g.ld_aux = P.data_ptr(), Tp
     return g
 
 
